@@ -1,0 +1,206 @@
+/*
+ * ictr.h -- C-ABI of the MI355X-native Gauss-Newton photometric tracker.
+ *
+ * Drop-in boundary for the per-frame tracking hot path of catree/InvCompCamTrack. The reference
+ * has NO C-ABI for this path: its boundary is the C++ class API in namespace CTR
+ * (camera.h:19-31, pose.h:18-40, odometer.h:21-30, utilities.h:46-82) that the two CLI drivers
+ * link statically (run_io_reprojection_test.cpp:189-223, run_track_nposes.cpp:185-259). This header
+ * mirrors those classes one method per function, with opaque handles, plain pointers and sizes,
+ * following the conventions of the reference's only real FFI (misc_src/triang.c + its ctypes
+ * callers, func_util_geom.py:582-606): caller-owned C-contiguous float32/float64 buffers, results
+ * written into caller-allocated outputs. Differences, all deliberate:
+ *   - every function returns an int status (0 = ok) instead of void; nothing throws across the ABI;
+ *     ictr_last_error() gives the message. (The reference ignores all errors.)
+ *   - counts are int64_t (the reference's ctypes callers pass c_longlong against C int).
+ *   - image pyramids are device-resident handles (ictr_pyramid) built by HIP kernels, replacing the
+ *     cv::Mat-typed util_constructpyramide (utilities.h:63-64); ictr_odometer_setpose_host keeps the
+ *     reference's literal "const float** level pointer" signature for callers that own host planes.
+ *   - ictr_batch_* runs B independent tracking problems per launch (the run_track_nposes pose-sample
+ *     axis, run_track_nposes.cpp:193); an ictr_odometer is a batch of one.
+ *
+ * include/ctr_shim.hpp re-creates namespace CTR {CamClass, PoseClass, OdometerClass} on top of
+ * these functions; INTEGRATION.md shows the ctypes binding.
+ *
+ * All hot-path arithmetic runs in hand-written HIP kernels for gfx950; there is no CPU fallback:
+ * every entry point that needs the GPU fails with ICTR_ERR_NO_DEVICE when none is usable.
+ */
+#ifndef ICTR_H
+#define ICTR_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICTR_OK 0
+#define ICTR_ERR_INVALID 1   /* bad argument */
+#define ICTR_ERR_NO_DEVICE 2 /* no usable HIP device */
+#define ICTR_ERR_HIP 3       /* a HIP runtime call failed */
+#define ICTR_ERR_STATE 4     /* call order violated (e.g. TrackPose before SetPose) */
+
+/* optparam, utilities.h:46-61 -- field order and types preserved verbatim */
+typedef struct ictr_optparam {
+  int maxpttrack;   /* SoA stride M of all point arrays; drivers round it up to a multiple of 4 */
+  int psz;          /* patch size P */
+  int pszd2;        /* P/2 */
+  int pszd2m3;      /* P + P/2 - 1 */
+  int novals;       /* P*P */
+  int lv_f;         /* coarsest pyramid level (first processed) */
+  int lv_l;         /* finest pyramid level (last processed) */
+  bool donorm;      /* point cloud + pose normalisation */
+  bool dopatchnorm; /* patch mean subtraction */
+  int maxiter;
+  float normdp_ratio;
+  int verbosity;
+} ictr_optparam;
+
+/* fills the derived fields exactly as run_io_reprojection_test.cpp:112-126 does */
+int ictr_optparam_init(ictr_optparam *op, int lv_f, int lv_l, int psz, int maxiter, float normdp_ratio,
+                       int donorm, int dopatchnorm, int maxpttrack, int verbosity);
+
+const char *ictr_last_error(void);
+int ictr_version(void);
+/* number of usable HIP devices (0 when none); never fails */
+int ictr_device_count(void);
+int ictr_set_device(int device);
+
+/* ------------------------------------------------------------------ CamClass (camera.h:19-31, camera.cpp:14-45) */
+typedef struct ictr_cam ictr_cam;
+int ictr_cam_create(ictr_cam **out, int noscales, const float *fc, const float *cc, const int *wh, int padding);
+void ictr_cam_destroy(ictr_cam *cam);
+float ictr_cam_getfx(const ictr_cam *cam, int sc);
+float ictr_cam_getfy(const ictr_cam *cam, int sc);
+float ictr_cam_getcx(const ictr_cam *cam, int sc);
+float ictr_cam_getcy(const ictr_cam *cam, int sc);
+float ictr_cam_getswo(const ictr_cam *cam, int sc);
+float ictr_cam_getsho(const ictr_cam *cam, int sc);
+float ictr_cam_getsw(const ictr_cam *cam, int sc);
+float ictr_cam_getsh(const ictr_cam *cam, int sc);
+
+/* ------------------------------------------------------------------ utilities.h:84-241 (SE(3) exp / log, host) */
+void ictr_se3_coeff_to_group_f(float *G12, const float *p6);
+void ictr_se3_coeff_to_group_d(double *G12, const double *p6);
+void ictr_se3_group_to_coeff_f(float *p6, const float *G12);
+void ictr_se3_group_to_coeff_d(double *p6, const double *G12);
+/* Hes.fullPivLu().solve(sumsd), odometer.cpp:509-515 (host copy of the device routine, for callers/tests) */
+void ictr_solve6(const float *H36, const float *b6, float *x6);
+
+/* ------------------------------------------------------------------ util_constructpyramide (utilities.cpp:14-52) */
+typedef struct ictr_pyramid ictr_pyramid;
+/* img: host, row-major f32, w x h. Builds lv_f+1 levels on the device: 2x2 box down-sampling, [-1 0 1]
+ * gradients with reflect-101 border, replicate (image) / zero (gradient) padding by `pad` pixels. */
+int ictr_pyramid_create(ictr_pyramid **out, const float *img, int w, int h, int lv_f, int getgrad, int pad);
+/* same, img already in device memory (stays caller-owned; only read during the call) */
+int ictr_pyramid_create_device(ictr_pyramid **out, const float *img_dev, int w, int h, int lv_f, int getgrad,
+                               int pad, void *hip_stream);
+/* adopts caller-built host planes (the reference's img_pyr / dx_pyr / dy_pyr arrays); dx/dy may be NULL */
+int ictr_pyramid_create_from_host_planes(ictr_pyramid **out, const float **img_pyr, const float **dx_pyr,
+                                         const float **dy_pyr, int w, int h, int lv_f, int pad);
+void ictr_pyramid_destroy(ictr_pyramid *pyr);
+int ictr_pyramid_levels(const ictr_pyramid *pyr);
+/* padded plane size of one level */
+int ictr_pyramid_level_dims(const ictr_pyramid *pyr, int level, int *sw, int *sh);
+/* which: 0 image, 1 dx, 2 dy */
+int ictr_pyramid_download(const ictr_pyramid *pyr, int level, int which, float *host_out);
+const float *ictr_pyramid_device_plane(const ictr_pyramid *pyr, int level, int which);
+
+/* util_getPatch / util_getPatch_grad (utilities.cpp:55-113, 115-189), batched over K centres.
+ * mids: host SoA x[K] then y[K]; outputs host, K*psz*psz each, patch-major. */
+int ictr_get_patch(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz, int dopatchnorm,
+                   float *out);
+int ictr_get_patch_grad(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz, int dopatchnorm,
+                        float *out, float *out_dx, float *out_dy);
+
+/* ------------------------------------------------------------------ PoseClass (pose.h:18-40) */
+typedef struct ictr_pose ictr_pose;
+/* cam and op are held by pointer for the object's lifetime, like the reference (pose.cpp:14-18);
+ * run_track_nposes.cpp:281 relies on that aliasing when it flips op.dopatchnorm. */
+int ictr_pose_create(ictr_pose **out, const ictr_cam *cam, const ictr_optparam *op);
+void ictr_pose_destroy(ictr_pose *pose);
+int ictr_pose_setpose_se3(ictr_pose *pose, const double *p_in, const double *meanshift3, double varval);
+int ictr_pose_addpose_se3(ictr_pose *pose, const float *dp6);
+int ictr_pose_subpose_se3(ictr_pose *pose, const float *dp6);
+int ictr_pose_getpose_se3(const ictr_pose *pose, double *p_out6);
+/* host SoA buffers with stride op->maxpttrack: pt3d X[M] Y[M] Z[M] -> pt2d x[M] y[M] */
+int ictr_pose_project_pt(const ictr_pose *pose, const float *pt3d, float *pt2d, int64_t nopoints, int sc);
+int ictr_pose_project_pt_save_rotated(const ictr_pose *pose, const float *pt3d, float *pt3d_rot, float *pt2d,
+                                      int64_t nopoints, int sc);
+/* current cpos_p[6] / cpos_G[12] (host copies) */
+int ictr_pose_get_state(const ictr_pose *pose, float *p6, float *G12);
+
+/* ------------------------------------------------------------------ OdometerClass (odometer.h:21-30) */
+typedef struct ictr_odometer ictr_odometer;
+int ictr_odometer_create(ictr_odometer **out, ictr_pose *pose, const ictr_optparam *op);
+void ictr_odometer_destroy(ictr_odometer *odo);
+/* Set3Dpoints (odometer.cpp:171-239). pt_in: host f64 SoA X[n] Y[n] Z[n] (stride nopoints_in).
+ * MUTATES pt_in when op->donorm, exactly like the reference (odometer.cpp:207-212). */
+int ictr_odometer_set3dpoints(ictr_odometer *odo, double *pt_in, int64_t nopoints_in);
+/* SetPose (odometer.cpp:241-255) with device pyramids; both are borrowed until the next SetPose */
+int ictr_odometer_setpose(ictr_odometer *odo, const double *p_in, const ictr_pyramid *pyr_ref,
+                          const ictr_pyramid *pyr_new);
+/* the reference's literal signature: host level-pointer arrays (uploaded on every call: PCIe-bound) */
+int ictr_odometer_setpose_host(ictr_odometer *odo, const double *p_in, const float **img_ref,
+                               const float **img_ref_dx, const float **img_ref_dy, const float **img_new);
+/* TrackPose (odometer.cpp:257-426): coarse-to-fine Gauss-Newton on the device, result in p_out[6] */
+int ictr_odometer_trackpose(ictr_odometer *odo, double *p_out);
+/* Get2DPoints (odometer.h:30): host SoA x[M] y[M] at level lv_l, valid after SetPose; owned by odo */
+const float *ictr_odometer_get2dpoints(ictr_odometer *odo);
+/* stream all of this odometer's kernels are enqueued on (hipStream_t); NULL = default stream */
+int ictr_odometer_set_stream(ictr_odometer *odo, void *hip_stream);
+
+/* ---- inspection (parity tests, profiling); not part of the reference surface ---- */
+typedef struct ictr_trace_rec {
+  int level;
+  int iter;
+  float H[36];
+  float b[6];
+  float dp[6];
+  float p[6];
+} ictr_trace_rec;
+/* enable before trackpose; records every executed (level, iteration) of problem 0 */
+int ictr_odometer_enable_trace(ictr_odometer *odo, int enable);
+int ictr_odometer_trace(ictr_odometer *odo, ictr_trace_rec *out, int64_t capacity, int64_t *count);
+/* which: 0 pat_ref 1 pat_ref_dx 2 pat_ref_dy (novals*M floats) 4 pt3d 5 pt3d_ref (3*M) 7 sd coefficients (16*M);
+ * 100+l: pt2d of level l (2*M). Copies device state to host_out. */
+int ictr_odometer_read_buffer(ictr_odometer *odo, int which, float *host_out, int64_t count);
+/* normalisation parameters of the last Set3Dpoints */
+int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double *varval);
+/* kernel variant for A/B runs: bit0 = stage the current-frame window through LDS */
+int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
+
+/* ------------------------------------------------------------------ batched engine (B independent problems) */
+typedef struct ictr_batch ictr_batch;
+/* All problems share cam and op; each has its own point set (<= op->maxpttrack), pose and frame pair. */
+int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ictr_optparam *op, int64_t nproblems);
+void ictr_batch_destroy(ictr_batch *b);
+int ictr_batch_set_stream(ictr_batch *b, void *hip_stream);
+int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in);
+int ictr_batch_setpose(ictr_batch *b, int64_t problem, const double *p_in, const ictr_pyramid *pyr_ref,
+                       const ictr_pyramid *pyr_new);
+/* enqueue SetPose's projection + the whole coarse-to-fine loop for every problem; asynchronous */
+int ictr_batch_track_async(ictr_batch *b);
+/* wait and fetch all poses: p_out[6*nproblems] */
+int ictr_batch_get_poses(ictr_batch *b, double *p_out);
+/* number of GN iterations each problem executed in the last track, per level summed: iters[nproblems] */
+int ictr_batch_get_iterations(ictr_batch *b, int *iters);
+int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out /* 2*M */);
+int ictr_batch_set_variant(ictr_batch *b, int variant);
+
+/* ---- distributed (points sharded over ranks): split phases so the caller can all-reduce ----
+ * The normal-equation block lives in a caller-visible device buffer: per problem 21 floats of H
+ * (upper triangle, row-major) + 6 floats of b  => red[nproblems][27]. With sharding enabled the
+ * accumulate kernels leave rank-local sums there and the *_finish kernels consume the reduced values. */
+int ictr_batch_enable_sharding(ictr_batch *b, int enable);
+float *ictr_batch_reduction_buffer(ictr_batch *b); /* device pointer, nproblems*27 floats */
+int ictr_batch_begin(ictr_batch *b);                  /* SetPose projection, all problems */
+int ictr_batch_level_accumulate(ictr_batch *b, int level);  /* steps 4-6 -> local H in red[] */
+int ictr_batch_level_finish(ictr_batch *b, int level);      /* adopt (reduced) H, reset iteration state */
+int ictr_batch_iter_accumulate(ictr_batch *b, int level);   /* steps 7-9a -> local b in red[] */
+int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on the (reduced) b */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICTR_H */

@@ -1,0 +1,74 @@
+// ictr_dev.h -- structures shared by the HIP kernels and the host-side ABI implementation.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ictr.h"
+
+namespace ictr {
+
+constexpr int kBlock = 256;        // threads per workgroup = 4 wave64
+constexpr int kWaves = kBlock / 64;
+constexpr int kCoefStride = 16;    // 12 steepest-descent coefficients per point, padded to one 64-B line
+constexpr int kHUnique = 21;       // upper triangle of the 6x6 normal matrix
+constexpr int kRedStride = 27;     // per problem: 21 (H) + 6 (b) in the reduction buffer
+constexpr int kPartHStride = 32;   // per block partial of H (21 padded to 32)
+constexpr int kPartBStride = 8;    // per block partial of b (6 padded)
+constexpr int kMaxGridX = 2048;    // 256 CUs x 8 resident workgroups: cap, then grid-stride
+
+// per pyramid level camera constants (camera.cpp:31-42), passed by value to the kernels
+struct LevelCam {
+  float fx, fy, cx, cy, swo, sho;
+  int sw;  // padded row stride, (int)getsw(level) as the reference passes it (odometer.cpp:286)
+};
+
+// device pointers of the four planes one problem reads at one level
+struct PlaneSet {
+  const float *ref, *dx, *dy, *cur;
+};
+
+// per-problem state living in device memory for the whole coarse-to-fine loop
+struct ProbState {
+  float p[6];    // cpos_p  (pose.h:54)
+  float G[12];   // cpos_G  (pose.h:53)
+  float H[36];   // Hes     (odometer.h:62)
+  float b[6];    // sumsd
+  float dp[6];   // delta_p
+  float normdp;
+  float normdp_init;
+  int it;           // iteration counter of the current level
+  int active;       // loop condition of odometer.cpp:344-346, evaluated on the device
+  int total_iters;  // executed GN iterations, all levels
+  int npts;         // nopoints of this problem
+  unsigned arrive;  // last-block ticket counter
+  int pad_;
+};
+
+struct DevTrace {
+  ictr_trace_rec *rec;
+  int *count;
+  int capacity;
+};
+
+// everything a kernel needs, passed by value (kernarg segment)
+struct EngineDev {
+  int B, M, P, n, nlev;  // nlev = lv_f+1
+  int lv_f, lv_l, maxiter;
+  float ratio;
+  int dopatchnorm;
+  int sharded;  // 1: accumulate kernels stop after writing rank-local sums to red[]
+  float *pt3d;      // [B][3M]  X..Y..Z..
+  float *pt3d_ref;  // [B][3M]  camera-frame points at the reference pose
+  float *pt2d;      // [B][nlev][2M]
+  float *T, *Gx, *Gy;  // [B][M*n] patch-major, the reference's pat_ref_all / _dx_all / _dy_all
+  float *coef;         // [B][M][16]
+  ProbState *st;       // [B]
+  const PlaneSet *planes;  // [B][nlev]
+  float *partH;  // [B][gridx][32]
+  float *partb;  // [B][gridx][8]
+  float *red;    // [B][27]
+  DevTrace trace;
+};
+
+}  // namespace ictr

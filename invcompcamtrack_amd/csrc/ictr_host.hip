@@ -1,0 +1,968 @@
+// ictr_host.hip -- implementation of the C-ABI in include/ictr.h: handle objects, device arenas and the
+// launch sequences. Host-side maths here is only what the reference also does per call on a handful of
+// scalars (pose normalisation pose.cpp:25-113, point-cloud normalisation odometer.cpp:171-239); everything
+// that touches pixels or points runs in the kernels of ictr_kernels.hip. There is no CPU fallback.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "ictr_dev.h"
+#include "se3_math.h"
+
+namespace ictr {
+void launch_pyr_copy(const float *, float *, int, int, int, int, hipStream_t);
+void launch_pyr_down(const float *, int, int, int, float *, int, int, int, int, hipStream_t);
+void launch_pyr_finish(float *, float *, float *, int, int, int, int, int, int, hipStream_t);
+void launch_getpatch(const float *, const float *, const float *, const float *, int, int, int, int, float *, float *,
+                     float *, hipStream_t);
+void launch_project_generic(const float *, float *, float *, int, int, const float *, LevelCam, hipStream_t);
+void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
+void launch_ref_level(const EngineDev &, const LevelCam &, int, int, hipStream_t);
+void launch_level_finish(const EngineDev &, hipStream_t);
+void launch_iter(const EngineDev &, const LevelCam &, int, int, int, hipStream_t);
+void launch_iter_finish(const EngineDev &, int, hipStream_t);
+}  // namespace ictr
+
+using namespace ictr;
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) return fail(ICTR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));   \
+  } while (0)
+
+extern "C" const char *ictr_last_error(void) { return g_err.c_str(); }
+extern "C" int ictr_version(void) { return 100; }
+extern "C" int ictr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int ictr_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  return ICTR_OK;
+}
+static int need_device() {
+  if (ictr_device_count() <= 0)
+    return fail(ICTR_ERR_NO_DEVICE, "no usable HIP device: the tracker has no CPU fallback");
+  return ICTR_OK;
+}
+
+extern "C" int ictr_optparam_init(ictr_optparam *op, int lv_f, int lv_l, int psz, int maxiter, float normdp_ratio,
+                                  int donorm, int dopatchnorm, int maxpttrack, int verbosity) {
+  if (!op) return fail(ICTR_ERR_INVALID, "op is NULL");
+  memset(op, 0, sizeof(*op));
+  op->lv_f = lv_f;
+  op->lv_l = lv_l;
+  op->psz = psz;
+  op->pszd2 = psz / 2;
+  op->pszd2m3 = psz + op->pszd2 - 1;
+  op->novals = psz * psz;
+  op->maxiter = maxiter;
+  op->normdp_ratio = normdp_ratio;
+  op->donorm = donorm != 0;
+  op->dopatchnorm = dopatchnorm != 0;
+  op->maxpttrack = maxpttrack;
+  const int r = op->maxpttrack % 4;  // SSEMULTIPL padding of the drivers (run_io_reprojection_test.cpp:123-126)
+  if (r > 0) op->maxpttrack += 4 - r;
+  op->verbosity = verbosity;
+  return ICTR_OK;
+}
+
+// ---------------------------------------------------------------- CamClass
+struct ictr_cam {
+  int noscales;
+  int padding;
+  int wh[2];
+  std::vector<float> fx, fy, cx, cy, swo, sho, sw, sh;
+};
+
+extern "C" int ictr_cam_create(ictr_cam **out, int noscales, const float *fc, const float *cc, const int *wh,
+                               int padding) {
+  if (!out || !fc || !cc || !wh || noscales < 1 || noscales > 16 || padding < 0)
+    return fail(ICTR_ERR_INVALID, "ictr_cam_create: bad arguments (noscales must be 1..16)");
+  ictr_cam *c = new ictr_cam;
+  c->noscales = noscales;
+  c->padding = padding;
+  c->wh[0] = wh[0];
+  c->wh[1] = wh[1];
+  for (auto *v : {&c->fx, &c->fy, &c->cx, &c->cy, &c->swo, &c->sho, &c->sw, &c->sh}) v->resize(noscales);
+  for (int i = 0; i < noscales; ++i) {
+    const float s = (float)(1 / pow(2, i));  // camera.cpp:33
+    c->fx[i] = s * fc[0];
+    c->fy[i] = s * fc[1];
+    c->cx[i] = s * cc[0];
+    c->cy[i] = s * cc[1];
+    c->swo[i] = s * (float)wh[0];
+    c->sho[i] = s * (float)wh[1];
+    c->sw[i] = c->swo[i] + 2 * padding;
+    c->sh[i] = c->sho[i] + 2 * padding;
+  }
+  *out = c;
+  return ICTR_OK;
+}
+extern "C" void ictr_cam_destroy(ictr_cam *cam) { delete cam; }
+#define CAMGET(name, field) \
+  extern "C" float ictr_cam_##name(const ictr_cam *cam, int sc) { return cam->field[sc]; }
+CAMGET(getfx, fx)
+CAMGET(getfy, fy)
+CAMGET(getcx, cx)
+CAMGET(getcy, cy)
+CAMGET(getswo, swo)
+CAMGET(getsho, sho)
+CAMGET(getsw, sw)
+CAMGET(getsh, sh)
+
+static LevelCam level_cam(const ictr_cam *c, int l) {
+  LevelCam lc;
+  lc.fx = c->fx[l];
+  lc.fy = c->fy[l];
+  lc.cx = c->cx[l];
+  lc.cy = c->cy[l];
+  lc.swo = c->swo[l];
+  lc.sho = c->sho[l];
+  lc.sw = (int)c->sw[l];
+  return lc;
+}
+
+// ---------------------------------------------------------------- SE(3) helpers on the host
+extern "C" void ictr_se3_coeff_to_group_f(float *G, const float *p) { se3_exp<float>(G, p); }
+extern "C" void ictr_se3_coeff_to_group_d(double *G, const double *p) { se3_exp<double>(G, p); }
+extern "C" void ictr_se3_group_to_coeff_f(float *p, const float *G) { se3_log<float>(p, G); }
+extern "C" void ictr_se3_group_to_coeff_d(double *p, const double *G) { se3_log<double>(p, G); }
+extern "C" void ictr_solve6(const float *H, const float *b, float *x) { lu_solve<6>(H, b, x); }
+
+// pose.cpp:25-76
+static void host_setpose(bool donorm, const double *p_in, const double *ms, double varval, float *p_f, float *G_f) {
+  double pn[6];
+  memcpy(pn, p_in, sizeof(pn));
+  if (donorm) {
+    double G[12];
+    se3_exp<double>(G, pn);
+    double t[3];
+    t[0] = -G[0] * G[3] - G[4] * G[7] - G[8] * G[11];
+    t[1] = -G[1] * G[3] - G[5] * G[7] - G[9] * G[11];
+    t[2] = -G[2] * G[3] - G[6] * G[7] - G[10] * G[11];
+    t[0] = (t[0] - ms[0]) / varval;
+    t[1] = (t[1] - ms[1]) / varval;
+    t[2] = (t[2] - ms[2]) / varval;
+    G[3] = -G[0] * t[0] - G[1] * t[1] - G[2] * t[2];
+    G[7] = -G[4] * t[0] - G[5] * t[1] - G[6] * t[2];
+    G[11] = -G[8] * t[0] - G[9] * t[1] - G[10] * t[2];
+    se3_log<double>(pn, G);
+  }
+  for (int i = 0; i < 6; ++i) p_f[i] = (float)pn[i];
+  se3_exp<float>(G_f, p_f);
+}
+// pose.cpp:79-113 (f32 G, f64 camera centre, f32 log: the reference's mixed precision is kept)
+static void host_getpose(bool donorm, const float *p_f, const float *G_f, const double *ms, double varval,
+                         double *p_out) {
+  float pu[6];
+  memcpy(pu, p_f, sizeof(pu));
+  if (donorm) {
+    float G[12];
+    memcpy(G, G_f, sizeof(G));
+    double t[3];
+    t[0] = (double)(-G[0] * G[3] - G[4] * G[7] - G[8] * G[11]);
+    t[1] = (double)(-G[1] * G[3] - G[5] * G[7] - G[9] * G[11]);
+    t[2] = (double)(-G[2] * G[3] - G[6] * G[7] - G[10] * G[11]);
+    t[0] = t[0] * varval + ms[0];
+    t[1] = t[1] * varval + ms[1];
+    t[2] = t[2] * varval + ms[2];
+    G[3] = (float)(-G[0] * t[0] - G[1] * t[1] - G[2] * t[2]);
+    G[7] = (float)(-G[4] * t[0] - G[5] * t[1] - G[6] * t[2]);
+    G[11] = (float)(-G[8] * t[0] - G[9] * t[1] - G[10] * t[2]);
+    se3_log<float>(pu, G);
+  }
+  for (int i = 0; i < 6; ++i) p_out[i] = (double)pu[i];
+}
+
+// ---------------------------------------------------------------- pyramid
+struct ictr_pyramid {
+  int nlev = 0, pad = 0, w0 = 0, h0 = 0, getgrad = 0;
+  std::vector<int> w, h, sw, sh;
+  std::vector<float *> img, dx, dy;  // device planes
+  float *arena = nullptr;
+};
+
+static void level_size(int w, int h, int level, int *wl, int *hl) {
+  auto half = [](int v) {  // cvRound(v*0.5), round-half-even, as cv::resize(dsize=Size(), fx=.5) sizes its output
+    const int q = v / 2;
+    if (v % 2 == 0) return q;
+    return (q % 2 == 0) ? q : q + 1;
+  };
+  for (int i = 0; i < level; ++i) {
+    w = half(w);
+    h = half(h);
+  }
+  *wl = w;
+  *hl = h;
+}
+
+static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad, int pad) {
+  if (!out || w < 1 || h < 1 || lv_f < 0 || lv_f > 15 || pad < 0)
+    return fail(ICTR_ERR_INVALID, "pyramid: bad arguments");
+  if (int rc = need_device()) return rc;
+  ictr_pyramid *p = new ictr_pyramid;
+  p->nlev = lv_f + 1;
+  p->pad = pad;
+  p->w0 = w;
+  p->h0 = h;
+  p->getgrad = getgrad;
+  size_t total = 0;
+  for (int l = 0; l <= lv_f; ++l) {
+    int wl, hl;
+    level_size(w, h, l, &wl, &hl);
+    if (wl < 1 || hl < 1) {
+      delete p;
+      return fail(ICTR_ERR_INVALID, "pyramid: level %d is empty", l);
+    }
+    p->w.push_back(wl);
+    p->h.push_back(hl);
+    p->sw.push_back(wl + 2 * pad);
+    p->sh.push_back(hl + 2 * pad);
+    size_t plane = (size_t)(wl + 2 * pad) * (hl + 2 * pad);
+    plane = (plane + 63) / 64 * 64;  // 256-B aligned planes
+    total += plane * 3;
+  }
+  hipError_t e = hipMalloc((void **)&p->arena, total * sizeof(float));
+  if (e != hipSuccess) {
+    delete p;
+    return fail(ICTR_ERR_HIP, "hipMalloc(%zu) failed: %s", total * sizeof(float), hipGetErrorString(e));
+  }
+  float *cur = p->arena;
+  for (int l = 0; l <= lv_f; ++l) {
+    size_t plane = (size_t)p->sw[l] * p->sh[l];
+    plane = (plane + 63) / 64 * 64;
+    p->img.push_back(cur);
+    p->dx.push_back(cur + plane);
+    p->dy.push_back(cur + 2 * plane);
+    cur += 3 * plane;
+  }
+  *out = p;
+  return ICTR_OK;
+}
+
+static int pyramid_build(ictr_pyramid *p, const float *img_dev, hipStream_t s) {
+  for (int l = 0; l < p->nlev; ++l) {
+    if (l == 0)
+      launch_pyr_copy(img_dev, p->img[0], p->w[0], p->h[0], p->pad, p->sw[0], s);
+    else
+      launch_pyr_down(p->img[l - 1], p->w[l - 1], p->h[l - 1], p->sw[l - 1], p->img[l], p->w[l], p->h[l], p->pad,
+                      p->sw[l], s);
+    launch_pyr_finish(p->img[l], p->dx[l], p->dy[l], p->w[l], p->h[l], p->pad, p->sw[l], p->sh[l], p->getgrad, s);
+  }
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+
+extern "C" int ictr_pyramid_create_device(ictr_pyramid **out, const float *img_dev, int w, int h, int lv_f, int getgrad,
+                                          int pad, void *hip_stream) {
+  if (!img_dev) return fail(ICTR_ERR_INVALID, "pyramid: img is NULL");
+  ictr_pyramid *p = nullptr;
+  if (int rc = pyramid_alloc(&p, w, h, lv_f, getgrad, pad)) return rc;
+  int rc = pyramid_build(p, img_dev, (hipStream_t)hip_stream);
+  if (rc) {
+    ictr_pyramid_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return ICTR_OK;
+}
+
+extern "C" int ictr_pyramid_create(ictr_pyramid **out, const float *img, int w, int h, int lv_f, int getgrad,
+                                   int pad) {
+  if (!img) return fail(ICTR_ERR_INVALID, "pyramid: img is NULL");
+  if (int rc = need_device()) return rc;
+  float *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, sizeof(float) * (size_t)w * h));
+  hipError_t e = hipMemcpy(d, img, sizeof(float) * (size_t)w * h, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    hipFree(d);
+    return fail(ICTR_ERR_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+  }
+  int rc = ictr_pyramid_create_device(out, d, w, h, lv_f, getgrad, pad, nullptr);
+  hipError_t e2 = hipDeviceSynchronize();
+  hipFree(d);
+  if (rc) return rc;
+  if (e2 != hipSuccess) return fail(ICTR_ERR_HIP, "pyramid kernels failed: %s", hipGetErrorString(e2));
+  return ICTR_OK;
+}
+
+extern "C" int ictr_pyramid_create_from_host_planes(ictr_pyramid **out, const float **img_pyr, const float **dx_pyr,
+                                                    const float **dy_pyr, int w, int h, int lv_f, int pad) {
+  if (!img_pyr) return fail(ICTR_ERR_INVALID, "pyramid: img_pyr is NULL");
+  ictr_pyramid *p = nullptr;
+  if (int rc = pyramid_alloc(&p, w, h, lv_f, dx_pyr && dy_pyr, pad)) return rc;
+  for (int l = 0; l <= lv_f; ++l) {
+    const size_t bytes = sizeof(float) * (size_t)p->sw[l] * p->sh[l];
+    hipError_t e = hipMemcpy(p->img[l], img_pyr[l], bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && dx_pyr && dy_pyr) {
+      e = hipMemcpy(p->dx[l], dx_pyr[l], bytes, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(p->dy[l], dy_pyr[l], bytes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+      ictr_pyramid_destroy(p);
+      return fail(ICTR_ERR_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = p;
+  return ICTR_OK;
+}
+
+extern "C" void ictr_pyramid_destroy(ictr_pyramid *p) {
+  if (!p) return;
+  if (p->arena) hipFree(p->arena);
+  delete p;
+}
+extern "C" int ictr_pyramid_levels(const ictr_pyramid *p) { return p ? p->nlev : 0; }
+extern "C" int ictr_pyramid_level_dims(const ictr_pyramid *p, int level, int *sw, int *sh) {
+  if (!p || level < 0 || level >= p->nlev) return fail(ICTR_ERR_INVALID, "pyramid: bad level");
+  if (sw) *sw = p->sw[level];
+  if (sh) *sh = p->sh[level];
+  return ICTR_OK;
+}
+static float *pyr_plane(const ictr_pyramid *p, int level, int which) {
+  if (!p || level < 0 || level >= p->nlev) return nullptr;
+  return which == 0 ? p->img[level] : which == 1 ? p->dx[level] : which == 2 ? p->dy[level] : nullptr;
+}
+extern "C" const float *ictr_pyramid_device_plane(const ictr_pyramid *p, int level, int which) {
+  return pyr_plane(p, level, which);
+}
+extern "C" int ictr_pyramid_download(const ictr_pyramid *p, int level, int which, float *host_out) {
+  const float *d = pyr_plane(p, level, which);
+  if (!d || !host_out) return fail(ICTR_ERR_INVALID, "pyramid_download: bad arguments");
+  HIPCHK(hipMemcpy(host_out, d, sizeof(float) * (size_t)p->sw[level] * p->sh[level], hipMemcpyDeviceToHost));
+  return ICTR_OK;
+}
+
+static int get_patch_impl(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz, int dopatchnorm,
+                          float *out, float *out_dx, float *out_dy, bool grad) {
+  if (!pyr || level < 0 || level >= pyr->nlev || !mids || !out || K < 0 || psz < 1 || psz > pyr->pad)
+    return fail(ICTR_ERR_INVALID, "get_patch: bad arguments (psz must be <= pyramid padding)");
+  if (grad && (!out_dx || !out_dy || !pyr->getgrad)) return fail(ICTR_ERR_INVALID, "get_patch_grad: no gradients");
+  if (K == 0) return ICTR_OK;
+  // centres must lie inside [0,swo] x [0,sho] like the callers guarantee (odometer.cpp:273-276)
+  for (int64_t i = 0; i < K; ++i)
+    if (!(mids[i] >= 0 && mids[i] <= (float)pyr->w[level] && mids[i + K] >= 0 && mids[i + K] <= (float)pyr->h[level]))
+      return fail(ICTR_ERR_INVALID, "get_patch: centre %lld outside the image", (long long)i);
+  const size_t nf = (size_t)K * psz * psz;
+  float *d_m = nullptr, *d_o = nullptr;
+  HIPCHK(hipMalloc((void **)&d_m, sizeof(float) * 2 * K));
+  hipError_t e = hipMalloc((void **)&d_o, sizeof(float) * nf * (grad ? 3 : 1));
+  if (e != hipSuccess) {
+    hipFree(d_m);
+    return fail(ICTR_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  e = hipMemcpy(d_m, mids, sizeof(float) * 2 * K, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_getpatch(pyr->img[level], grad ? pyr->dx[level] : nullptr, grad ? pyr->dy[level] : nullptr, d_m, (int)K, psz,
+                    pyr->sw[level], dopatchnorm, d_o, grad ? d_o + nf : nullptr, grad ? d_o + 2 * nf : nullptr, nullptr);
+    e = hipMemcpy(out, d_o, sizeof(float) * nf, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && grad) {
+      e = hipMemcpy(out_dx, d_o + nf, sizeof(float) * nf, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out_dy, d_o + 2 * nf, sizeof(float) * nf, hipMemcpyDeviceToHost);
+    }
+  }
+  hipFree(d_m);
+  hipFree(d_o);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "get_patch failed: %s", hipGetErrorString(e));
+  return ICTR_OK;
+}
+extern "C" int ictr_get_patch(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz,
+                              int dopatchnorm, float *out) {
+  return get_patch_impl(pyr, level, mids, K, psz, dopatchnorm, out, nullptr, nullptr, false);
+}
+extern "C" int ictr_get_patch_grad(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz,
+                                   int dopatchnorm, float *out, float *out_dx, float *out_dy) {
+  return get_patch_impl(pyr, level, mids, K, psz, dopatchnorm, out, out_dx, out_dy, true);
+}
+
+// ---------------------------------------------------------------- PoseClass
+struct ictr_pose {
+  const ictr_cam *cam;
+  const ictr_optparam *op;
+  double meanshift[3] = {0, 0, 0};
+  double varval = 0;
+  float p[6] = {0, 0, 0, 0, 0, 0};
+  float G[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+};
+
+extern "C" int ictr_pose_create(ictr_pose **out, const ictr_cam *cam, const ictr_optparam *op) {
+  if (!out || !cam || !op) return fail(ICTR_ERR_INVALID, "ictr_pose_create: NULL argument");
+  ictr_pose *p = new ictr_pose;
+  p->cam = cam;
+  p->op = op;
+  *out = p;
+  return ICTR_OK;
+}
+extern "C" void ictr_pose_destroy(ictr_pose *pose) { delete pose; }
+extern "C" int ictr_pose_setpose_se3(ictr_pose *pose, const double *p_in, const double *meanshift3, double varval) {
+  if (!pose || !p_in) return fail(ICTR_ERR_INVALID, "setpose_se3: NULL argument");
+  if (pose->op->donorm) {
+    if (!meanshift3) return fail(ICTR_ERR_INVALID, "setpose_se3: donorm needs meanshift");
+    pose->varval = varval;
+    memcpy(pose->meanshift, meanshift3, sizeof(double) * 3);
+  }
+  host_setpose(pose->op->donorm, p_in, pose->meanshift, pose->varval, pose->p, pose->G);
+  return ICTR_OK;
+}
+extern "C" int ictr_pose_addpose_se3(ictr_pose *pose, const float *dp) {
+  if (!pose || !dp) return fail(ICTR_ERR_INVALID, "addpose_se3: NULL argument");
+  for (int i = 0; i < 6; ++i) pose->p[i] += dp[i];
+  se3_exp<float>(pose->G, pose->p);
+  return ICTR_OK;
+}
+extern "C" int ictr_pose_subpose_se3(ictr_pose *pose, const float *dp) {
+  if (!pose || !dp) return fail(ICTR_ERR_INVALID, "subpose_se3: NULL argument");
+  for (int i = 0; i < 6; ++i) pose->p[i] -= dp[i];
+  se3_exp<float>(pose->G, pose->p);
+  return ICTR_OK;
+}
+extern "C" int ictr_pose_getpose_se3(const ictr_pose *pose, double *p_out) {
+  if (!pose || !p_out) return fail(ICTR_ERR_INVALID, "getpose_se3: NULL argument");
+  host_getpose(pose->op->donorm, pose->p, pose->G, pose->meanshift, pose->varval, p_out);
+  return ICTR_OK;
+}
+extern "C" int ictr_pose_get_state(const ictr_pose *pose, float *p6, float *G12) {
+  if (!pose) return fail(ICTR_ERR_INVALID, "pose is NULL");
+  if (p6) memcpy(p6, pose->p, sizeof(float) * 6);
+  if (G12) memcpy(G12, pose->G, sizeof(float) * 12);
+  return ICTR_OK;
+}
+
+static int project_impl(const ictr_pose *pose, const float *pt3d, float *pt3d_rot, float *pt2d, int64_t nopoints,
+                        int sc) {
+  if (!pose || !pt3d || !pt2d || nopoints < 0 || sc < 0 || sc >= pose->cam->noscales)
+    return fail(ICTR_ERR_INVALID, "project_pt: bad arguments");
+  if (int rc = need_device()) return rc;
+  const int M = pose->op->maxpttrack;
+  if (nopoints > M) return fail(ICTR_ERR_INVALID, "project_pt: nopoints > maxpttrack");
+  if (nopoints == 0) return ICTR_OK;
+  float *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, sizeof(float) * (size_t)(8 * M + 12)));
+  float *d3 = d, *dr = d + 3 * M, *d2 = d + 6 * M, *dG = d + 8 * M;
+  hipError_t e = hipMemcpy(d3, pt3d, sizeof(float) * 3 * M, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dG, pose->G, sizeof(float) * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d2, pt2d, sizeof(float) * 2 * M, hipMemcpyHostToDevice);
+  if (e == hipSuccess && pt3d_rot) e = hipMemcpy(dr, pt3d_rot, sizeof(float) * 3 * M, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_project_generic(d3, pt3d_rot ? dr : nullptr, d2, (int)nopoints, M, dG, level_cam(pose->cam, sc), nullptr);
+    e = hipMemcpy(pt2d, d2, sizeof(float) * 2 * M, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && pt3d_rot) e = hipMemcpy(pt3d_rot, dr, sizeof(float) * 3 * M, hipMemcpyDeviceToHost);
+  }
+  hipFree(d);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "project_pt failed: %s", hipGetErrorString(e));
+  return ICTR_OK;
+}
+extern "C" int ictr_pose_project_pt(const ictr_pose *pose, const float *pt3d, float *pt2d, int64_t nopoints, int sc) {
+  return project_impl(pose, pt3d, nullptr, pt2d, nopoints, sc);
+}
+extern "C" int ictr_pose_project_pt_save_rotated(const ictr_pose *pose, const float *pt3d, float *pt3d_rot,
+                                                 float *pt2d, int64_t nopoints, int sc) {
+  if (!pt3d_rot) return fail(ICTR_ERR_INVALID, "project_pt_save_rotated: pt3d_rot is NULL");
+  return project_impl(pose, pt3d, pt3d_rot, pt2d, nopoints, sc);
+}
+
+// ---------------------------------------------------------------- batched engine
+struct ProbHost {
+  int npts = 0;
+  double meanshift[3] = {0, 0, 0};
+  double varval = 0;
+  float p[6] = {0, 0, 0, 0, 0, 0};
+  float G[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  const ictr_pyramid *ref = nullptr, *cur = nullptr;
+  bool pose_set = false;
+  int iters = 0;
+};
+
+struct ictr_batch {
+  const ictr_cam *cam = nullptr;
+  const ictr_optparam *op = nullptr;
+  int B = 0, M = 0, n = 0, nlev = 0, P = 0;
+  hipStream_t stream = nullptr;
+  int variant = 0;
+  int sharded = 0;
+  int gridx = 1;
+  bool trace_on = false;
+  bool projected = false;
+  // device
+  float *d_pt3d = nullptr, *d_pt3d_ref = nullptr, *d_pt2d = nullptr, *d_T = nullptr, *d_Gx = nullptr,
+        *d_Gy = nullptr, *d_coef = nullptr, *d_partH = nullptr, *d_partb = nullptr, *d_red = nullptr;
+  ProbState *d_st = nullptr;
+  PlaneSet *d_planes = nullptr;
+  ictr_trace_rec *d_trace = nullptr;
+  int *d_trace_count = nullptr;
+  int trace_cap = 0;
+  // host mirrors
+  std::vector<ProbHost> probs;
+  std::vector<ProbState> h_st;
+  std::vector<PlaneSet> h_planes;
+  std::vector<float> h_pt2d;  // Get2DPoints mirror of problem 0 (or scratch)
+  std::vector<float> h_stage;
+};
+
+static void batch_free(ictr_batch *b) {
+  if (!b) return;
+  for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
+                  (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
+                  (void *)b->d_st, (void *)b->d_planes, (void *)b->d_trace, (void *)b->d_trace_count})
+    if (p) hipFree(p);
+  delete b;
+}
+
+static EngineDev engine_dev(const ictr_batch *b) {
+  EngineDev e;
+  e.B = b->B;
+  e.M = b->M;
+  e.P = b->P;
+  e.n = b->n;
+  e.nlev = b->nlev;
+  e.lv_f = b->op->lv_f;
+  e.lv_l = b->op->lv_l;
+  e.maxiter = b->op->maxiter;
+  e.ratio = b->op->normdp_ratio;
+  e.dopatchnorm = b->op->dopatchnorm ? 1 : 0;
+  e.sharded = b->sharded;
+  e.pt3d = b->d_pt3d;
+  e.pt3d_ref = b->d_pt3d_ref;
+  e.pt2d = b->d_pt2d;
+  e.T = b->d_T;
+  e.Gx = b->d_Gx;
+  e.Gy = b->d_Gy;
+  e.coef = b->d_coef;
+  e.st = b->d_st;
+  e.planes = b->d_planes;
+  e.partH = b->d_partH;
+  e.partb = b->d_partb;
+  e.red = b->d_red;
+  e.trace.rec = b->trace_on ? b->d_trace : nullptr;
+  e.trace.count = b->d_trace_count;
+  e.trace.capacity = b->trace_cap;
+  return e;
+}
+
+static int check_op(const ictr_optparam *op, const ictr_cam *cam) {
+  if (op->psz < 1 || op->psz > 64) return fail(ICTR_ERR_INVALID, "psz must be 1..64");
+  if (op->novals != op->psz * op->psz || op->pszd2 != op->psz / 2)
+    return fail(ICTR_ERR_INVALID, "optparam derived fields inconsistent (use ictr_optparam_init)");
+  if (op->lv_l < 0 || op->lv_f < op->lv_l || op->lv_f >= cam->noscales)
+    return fail(ICTR_ERR_INVALID, "need 0 <= lv_l <= lv_f < cam.noscales");
+  if (op->maxpttrack < 1) return fail(ICTR_ERR_INVALID, "maxpttrack must be >= 1");
+  if (cam->padding < op->psz) return fail(ICTR_ERR_INVALID, "camera padding must be >= psz");
+  return ICTR_OK;
+}
+
+extern "C" int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ictr_optparam *op, int64_t nproblems) {
+  if (!out || !cam || !op || nproblems < 1 || nproblems > 65535)
+    return fail(ICTR_ERR_INVALID, "batch_create: bad arguments (1..65535 problems)");
+  if (int rc = check_op(op, cam)) return rc;
+  if (int rc = need_device()) return rc;
+  ictr_batch *b = new ictr_batch;
+  b->cam = cam;
+  b->op = op;
+  b->B = (int)nproblems;
+  b->M = op->maxpttrack;
+  b->P = op->psz;
+  b->n = op->novals;
+  b->nlev = op->lv_f + 1;
+  const size_t B = b->B, M = b->M, n = b->n, L = b->nlev;
+  const int ppw = (b->n <= 64 && 64 % b->n == 0) ? 64 / b->n : 1;
+  const int64_t groups = (b->M + ppw - 1) / ppw;
+  // workgroups per problem: enough to cover the points once, capped so that B problems together stay near
+  // 256 CUs x 8 resident workgroups x 2 (the rest is grid-strided)
+  const int64_t cap = std::min<int64_t>(kMaxGridX, std::max<int64_t>(64, 2 * kMaxGridX / (int64_t)B));
+  b->gridx = (int)std::min<int64_t>(std::max<int64_t>((groups + kWaves - 1) / kWaves, 1), cap);
+  b->trace_cap = std::max(1, (int)L * std::max(1, op->maxiter));
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void **p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+    if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+  };
+  alloc((void **)&b->d_pt3d, sizeof(float) * B * 3 * M);
+  alloc((void **)&b->d_pt3d_ref, sizeof(float) * B * 3 * M);
+  alloc((void **)&b->d_pt2d, sizeof(float) * B * L * 2 * M);
+  alloc((void **)&b->d_T, sizeof(float) * B * M * n);
+  alloc((void **)&b->d_Gx, sizeof(float) * B * M * n);
+  alloc((void **)&b->d_Gy, sizeof(float) * B * M * n);
+  alloc((void **)&b->d_coef, sizeof(float) * B * M * kCoefStride);
+  alloc((void **)&b->d_partH, sizeof(float) * B * b->gridx * kPartHStride);
+  alloc((void **)&b->d_partb, sizeof(float) * B * b->gridx * kPartBStride);
+  alloc((void **)&b->d_red, sizeof(float) * B * kRedStride);
+  alloc((void **)&b->d_st, sizeof(ProbState) * B);
+  alloc((void **)&b->d_planes, sizeof(PlaneSet) * B * L);
+  alloc((void **)&b->d_trace, sizeof(ictr_trace_rec) * b->trace_cap);
+  alloc((void **)&b->d_trace_count, sizeof(int));
+  if (e != hipSuccess) {
+    batch_free(b);
+    return fail(ICTR_ERR_HIP, "batch_create: device allocation failed: %s", hipGetErrorString(e));
+  }
+  b->probs.resize(B);
+  b->h_st.resize(B);
+  b->h_planes.resize(B * L);
+  b->h_pt2d.assign(2 * M, 0.0f);
+  b->h_stage.assign(3 * M, 0.0f);
+  *out = b;
+  return ICTR_OK;
+}
+extern "C" void ictr_batch_destroy(ictr_batch *b) { batch_free(b); }
+extern "C" int ictr_batch_set_stream(ictr_batch *b, void *hip_stream) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  b->stream = (hipStream_t)hip_stream;
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_set_variant(ictr_batch *b, int variant) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  b->variant = variant;
+  return ICTR_OK;
+}
+
+// odometer.cpp:171-239 (ResetOdometer + normalisation + f64->f32 SoA)
+extern "C" int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in) {
+  if (!b || problem < 0 || problem >= b->B || nopoints_in < 0 || (nopoints_in > 0 && !pt_in))
+    return fail(ICTR_ERR_INVALID, "set3dpoints: bad arguments");
+  ProbHost &ph = b->probs[problem];
+  const size_t M = b->M, n = b->n;
+  // ResetOdometer (odometer.cpp:580-609): patch / sd state of this problem back to zero
+  HIPCHK(hipMemsetAsync(b->d_T + problem * M * n, 0, sizeof(float) * M * n, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_Gx + problem * M * n, 0, sizeof(float) * M * n, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_Gy + problem * M * n, 0, sizeof(float) * M * n, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_coef + problem * M * kCoefStride, 0, sizeof(float) * M * kCoefStride, b->stream));
+  ph.meanshift[0] = ph.meanshift[1] = ph.meanshift[2] = 0;
+  ph.varval = 0;
+  ph.npts = (int)std::min<int64_t>(nopoints_in, b->M);
+  ph.pose_set = false;
+  const int np = ph.npts;
+  double *p1 = pt_in, *p2 = pt_in + nopoints_in, *p3 = pt_in + 2 * nopoints_in;
+  std::fill(b->h_stage.begin(), b->h_stage.end(), 0.0f);
+  float *s = b->h_stage.data();
+  if (b->op->donorm) {
+    const double nd = (double)np;
+    for (int i = 0; i < np; ++i) ph.meanshift[0] += p1[i];
+    for (int i = 0; i < np; ++i) ph.meanshift[1] += p2[i];
+    for (int i = 0; i < np; ++i) ph.meanshift[2] += p3[i];
+    ph.meanshift[0] /= nd;
+    ph.meanshift[1] /= nd;
+    ph.meanshift[2] /= nd;
+    for (int i = 0; i < np; ++i) {  // writes back into the caller's array, like odometer.cpp:207-212
+      p1[i] -= ph.meanshift[0];
+      p2[i] -= ph.meanshift[1];
+      p3[i] -= ph.meanshift[2];
+      ph.varval += p1[i] * p1[i] + p2[i] * p2[i] + p3[i] * p3[i];
+    }
+    ph.varval /= nd;  // mean squared radius (no sqrt), odometer.cpp:214
+    for (int i = 0; i < np; ++i) {
+      s[i] = (float)(p1[i] / ph.varval);
+      s[i + M] = (float)(p2[i] / ph.varval);
+      s[i + 2 * M] = (float)(p3[i] / ph.varval);
+    }
+  } else {
+    for (int i = 0; i < np; ++i) {
+      s[i] = (float)p1[i];
+      s[i + M] = (float)p2[i];
+      s[i + 2 * M] = (float)p3[i];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(b->d_pt3d + problem * 3 * M, s, sizeof(float) * 3 * M, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));  // h_stage is reused by the next call
+  return ICTR_OK;
+}
+
+extern "C" int ictr_batch_setpose(ictr_batch *b, int64_t problem, const double *p_in, const ictr_pyramid *pyr_ref,
+                                  const ictr_pyramid *pyr_new) {
+  if (!b || problem < 0 || problem >= b->B || !p_in || !pyr_ref || !pyr_new)
+    return fail(ICTR_ERR_INVALID, "setpose: bad arguments");
+  for (const ictr_pyramid *py : {pyr_ref, pyr_new}) {
+    if (py->nlev < b->nlev || py->pad != b->cam->padding)
+      return fail(ICTR_ERR_INVALID, "setpose: pyramid has %d levels / pad %d, engine needs %d / %d", py->nlev, py->pad,
+                  b->nlev, b->cam->padding);
+    for (int l = 0; l < b->nlev; ++l)
+      if (py->sw[l] != (int)b->cam->sw[l] || py->sh[l] < (int)b->cam->sh[l])
+        return fail(ICTR_ERR_INVALID, "setpose: pyramid level %d is %dx%d, camera expects %dx%d", l, py->sw[l],
+                    py->sh[l], (int)b->cam->sw[l], (int)b->cam->sh[l]);
+  }
+  if (!pyr_ref->getgrad) return fail(ICTR_ERR_INVALID, "setpose: reference pyramid has no gradients");
+  ProbHost &ph = b->probs[problem];
+  host_setpose(b->op->donorm, p_in, ph.meanshift, ph.varval, ph.p, ph.G);
+  ph.ref = pyr_ref;
+  ph.cur = pyr_new;
+  ph.pose_set = true;
+  b->projected = false;
+  return ICTR_OK;
+}
+
+// upload poses + plane tables, zero the tickets, run step 3 for every problem
+extern "C" int ictr_batch_begin(ictr_batch *b) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (int rc = check_op(b->op, b->cam)) return rc;
+  if (b->op->maxpttrack != b->M || b->op->psz != b->P || b->op->lv_f + 1 != b->nlev)
+    return fail(ICTR_ERR_STATE, "optparam maxpttrack/psz/lv_f changed after creation");
+  int maxpts = 0;
+  for (int i = 0; i < b->B; ++i) {
+    const ProbHost &ph = b->probs[i];
+    if (!ph.pose_set) return fail(ICTR_ERR_STATE, "problem %d: SetPose has not been called", i);
+    ProbState &st = b->h_st[i];
+    memset(&st, 0, sizeof(st));
+    memcpy(st.p, ph.p, sizeof(st.p));
+    memcpy(st.G, ph.G, sizeof(st.G));
+    st.npts = ph.npts;
+    st.normdp = st.normdp_init = 1e-10f;
+    maxpts = std::max(maxpts, ph.npts);
+    for (int l = 0; l < b->nlev; ++l) {
+      PlaneSet &ps = b->h_planes[(size_t)i * b->nlev + l];
+      ps.ref = ph.ref->img[l];
+      ps.dx = ph.ref->dx[l];
+      ps.dy = ph.ref->dy[l];
+      ps.cur = ph.cur->img[l];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(b->d_st, b->h_st.data(), sizeof(ProbState) * b->B, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_planes, b->h_planes.data(), sizeof(PlaneSet) * b->h_planes.size(), hipMemcpyHostToDevice,
+                        b->stream));
+  HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));
+  if (maxpts > 0) {
+    LevelCam cams[16];
+    for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
+    launch_project_ref(engine_dev(b), cams, maxpts, b->stream);
+  }
+  HIPCHK(hipGetLastError());
+  b->projected = true;
+  return ICTR_OK;
+}
+
+extern "C" int ictr_batch_enable_sharding(ictr_batch *b, int enable) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  b->sharded = enable ? 1 : 0;
+  return ICTR_OK;
+}
+extern "C" float *ictr_batch_reduction_buffer(ictr_batch *b) { return b ? b->d_red : nullptr; }
+
+static int level_ok(ictr_batch *b, int level) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (!b->projected) return fail(ICTR_ERR_STATE, "ictr_batch_begin has not run since the last SetPose");
+  if (level < b->op->lv_l || level > b->op->lv_f) return fail(ICTR_ERR_INVALID, "level out of range");
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_level_accumulate(ictr_batch *b, int level) {
+  if (int rc = level_ok(b, level)) return rc;
+  launch_ref_level(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->stream);
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_level_finish(ictr_batch *b, int level) {
+  if (int rc = level_ok(b, level)) return rc;
+  if (b->sharded) launch_level_finish(engine_dev(b), b->stream);
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_iter_accumulate(ictr_batch *b, int level) {
+  if (int rc = level_ok(b, level)) return rc;
+  launch_iter(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->stream);
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
+  if (int rc = level_ok(b, level)) return rc;
+  if (b->sharded) launch_iter_finish(engine_dev(b), level, b->stream);
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+
+extern "C" int ictr_batch_track_async(ictr_batch *b) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (b->sharded) return fail(ICTR_ERR_STATE, "sharded batches are driven phase by phase (see ictr.h)");
+  if (int rc = ictr_batch_begin(b)) return rc;
+  const EngineDev e = engine_dev(b);
+  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
+    const LevelCam lc = level_cam(b->cam, sl);
+    launch_ref_level(e, lc, sl, b->gridx, b->stream);
+    for (int it = 0; it < b->op->maxiter; ++it) launch_iter(e, lc, sl, b->gridx, b->variant, b->stream);
+  }
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+
+static int batch_fetch_state(ictr_batch *b) {
+  HIPCHK(hipMemcpyAsync(b->h_st.data(), b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int i = 0; i < b->B; ++i) {
+    memcpy(b->probs[i].p, b->h_st[i].p, sizeof(float) * 6);
+    memcpy(b->probs[i].G, b->h_st[i].G, sizeof(float) * 12);
+    b->probs[i].iters = b->h_st[i].total_iters;
+  }
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_get_poses(ictr_batch *b, double *p_out) {
+  if (!b || !p_out) return fail(ICTR_ERR_INVALID, "get_poses: NULL argument");
+  if (int rc = batch_fetch_state(b)) return rc;
+  for (int i = 0; i < b->B; ++i) {
+    const ProbHost &ph = b->probs[i];
+    host_getpose(b->op->donorm, ph.p, ph.G, ph.meanshift, ph.varval, p_out + 6 * i);
+  }
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_get_iterations(ictr_batch *b, int *iters) {
+  if (!b || !iters) return fail(ICTR_ERR_INVALID, "get_iterations: NULL argument");
+  for (int i = 0; i < b->B; ++i) iters[i] = b->probs[i].iters;
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out) {
+  if (!b || problem < 0 || problem >= b->B || !host_out) return fail(ICTR_ERR_INVALID, "get2dpoints: bad arguments");
+  if (!b->projected)
+    if (int rc = ictr_batch_begin(b)) return rc;
+  const size_t M = b->M;
+  HIPCHK(hipMemcpyAsync(host_out, b->d_pt2d + ((size_t)problem * b->nlev + b->op->lv_l) * 2 * M, sizeof(float) * 2 * M,
+                        hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ICTR_OK;
+}
+
+// ---------------------------------------------------------------- OdometerClass = batch of one + a PoseClass
+struct ictr_odometer {
+  ictr_batch *b = nullptr;
+  ictr_pose *pose = nullptr;
+  ictr_pyramid *own_ref = nullptr, *own_new = nullptr;  // uploads made by setpose_host
+};
+
+extern "C" int ictr_odometer_create(ictr_odometer **out, ictr_pose *pose, const ictr_optparam *op) {
+  if (!out || !pose || !op) return fail(ICTR_ERR_INVALID, "odometer_create: NULL argument");
+  ictr_batch *b = nullptr;
+  if (int rc = ictr_batch_create(&b, pose->cam, op, 1)) return rc;
+  ictr_odometer *o = new ictr_odometer;
+  o->b = b;
+  o->pose = pose;
+  *out = o;
+  return ICTR_OK;
+}
+extern "C" void ictr_odometer_destroy(ictr_odometer *o) {
+  if (!o) return;
+  ictr_pyramid_destroy(o->own_ref);
+  ictr_pyramid_destroy(o->own_new);
+  batch_free(o->b);
+  delete o;
+}
+extern "C" int ictr_odometer_set_stream(ictr_odometer *o, void *s) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  return ictr_batch_set_stream(o->b, s);
+}
+extern "C" int ictr_odometer_set_variant(ictr_odometer *o, int v) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  return ictr_batch_set_variant(o->b, v);
+}
+extern "C" int ictr_odometer_set3dpoints(ictr_odometer *o, double *pt_in, int64_t nopoints_in) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  return ictr_batch_set3dpoints(o->b, 0, pt_in, nopoints_in);
+}
+extern "C" int ictr_odometer_setpose(ictr_odometer *o, const double *p_in, const ictr_pyramid *pyr_ref,
+                                     const ictr_pyramid *pyr_new) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  if (int rc = ictr_batch_setpose(o->b, 0, p_in, pyr_ref, pyr_new)) return rc;
+  // PoseClass state follows (pose.cpp:25-76 is invoked through the odometer in the reference)
+  ProbHost &ph = o->b->probs[0];
+  memcpy(o->pose->meanshift, ph.meanshift, sizeof(ph.meanshift));
+  o->pose->varval = ph.varval;
+  memcpy(o->pose->p, ph.p, sizeof(ph.p));
+  memcpy(o->pose->G, ph.G, sizeof(ph.G));
+  // step 3 now, so Get2DPoints is valid right after SetPose like in the reference
+  return ictr_batch_begin(o->b);
+}
+extern "C" int ictr_odometer_setpose_host(ictr_odometer *o, const double *p_in, const float **img_ref,
+                                          const float **img_ref_dx, const float **img_ref_dy, const float **img_new) {
+  if (!o || !img_ref || !img_ref_dx || !img_ref_dy || !img_new)
+    return fail(ICTR_ERR_INVALID, "setpose_host: NULL argument");
+  const ictr_cam *c = o->b->cam;
+  ictr_pyramid_destroy(o->own_ref);
+  ictr_pyramid_destroy(o->own_new);
+  o->own_ref = o->own_new = nullptr;
+  if (int rc = ictr_pyramid_create_from_host_planes(&o->own_ref, img_ref, img_ref_dx, img_ref_dy, c->wh[0], c->wh[1],
+                                                    o->b->op->lv_f, c->padding))
+    return rc;
+  if (int rc = ictr_pyramid_create_from_host_planes(&o->own_new, img_new, nullptr, nullptr, c->wh[0], c->wh[1],
+                                                    o->b->op->lv_f, c->padding))
+    return rc;
+  return ictr_odometer_setpose(o, p_in, o->own_ref, o->own_new);
+}
+extern "C" int ictr_odometer_trackpose(ictr_odometer *o, double *p_out) {
+  if (!o || !p_out) return fail(ICTR_ERR_INVALID, "trackpose: NULL argument");
+  ictr_batch *b = o->b;
+  if (!b->probs[0].pose_set) return fail(ICTR_ERR_STATE, "TrackPose before SetPose");
+  if (!b->projected)
+    if (int rc = ictr_batch_begin(b)) return rc;
+  const EngineDev e = engine_dev(b);
+  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
+    const LevelCam lc = level_cam(b->cam, sl);
+    launch_ref_level(e, lc, sl, b->gridx, b->stream);
+    for (int it = 0; it < b->op->maxiter; ++it) launch_iter(e, lc, sl, b->gridx, b->variant, b->stream);
+  }
+  HIPCHK(hipGetLastError());
+  if (int rc = batch_fetch_state(b)) return rc;
+  memcpy(o->pose->p, b->probs[0].p, sizeof(float) * 6);
+  memcpy(o->pose->G, b->probs[0].G, sizeof(float) * 12);
+  return ictr_pose_getpose_se3(o->pose, p_out);
+}
+extern "C" const float *ictr_odometer_get2dpoints(ictr_odometer *o) {
+  if (!o) return nullptr;
+  if (ictr_batch_get2dpoints(o->b, 0, o->b->h_pt2d.data()) != ICTR_OK) return nullptr;
+  return o->b->h_pt2d.data();
+}
+extern "C" int ictr_odometer_enable_trace(ictr_odometer *o, int enable) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  o->b->trace_on = enable != 0;
+  return ICTR_OK;
+}
+extern "C" int ictr_odometer_trace(ictr_odometer *o, ictr_trace_rec *out, int64_t capacity, int64_t *count) {
+  if (!o || !count) return fail(ICTR_ERR_INVALID, "trace: NULL argument");
+  int c = 0;
+  HIPCHK(hipMemcpy(&c, o->b->d_trace_count, sizeof(int), hipMemcpyDeviceToHost));
+  c = std::min(c, o->b->trace_cap);
+  *count = c;
+  const int64_t ncopy = std::min<int64_t>(c, capacity);
+  if (out && ncopy > 0) HIPCHK(hipMemcpy(out, o->b->d_trace, sizeof(ictr_trace_rec) * ncopy, hipMemcpyDeviceToHost));
+  return ICTR_OK;
+}
+extern "C" int ictr_odometer_read_buffer(ictr_odometer *o, int which, float *host_out, int64_t count) {
+  if (!o || !host_out || count < 0) return fail(ICTR_ERR_INVALID, "read_buffer: bad arguments");
+  ictr_batch *b = o->b;
+  const size_t M = b->M, n = b->n;
+  const float *src = nullptr;
+  size_t avail = 0;
+  switch (which) {
+    case 0: src = b->d_T; avail = M * n; break;
+    case 1: src = b->d_Gx; avail = M * n; break;
+    case 2: src = b->d_Gy; avail = M * n; break;
+    case 4: src = b->d_pt3d; avail = 3 * M; break;
+    case 5: src = b->d_pt3d_ref; avail = 3 * M; break;
+    case 7: src = b->d_coef; avail = M * kCoefStride; break;
+    default:
+      if (which >= 100 && which < 100 + b->nlev) {
+        src = b->d_pt2d + (size_t)(which - 100) * 2 * M;
+        avail = 2 * M;
+      }
+  }
+  if (!src || (size_t)count > avail) return fail(ICTR_ERR_INVALID, "read_buffer: unknown buffer or count too large");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(host_out, src, sizeof(float) * count, hipMemcpyDeviceToHost));
+  return ICTR_OK;
+}
+extern "C" int ictr_odometer_get_norm(const ictr_odometer *o, double *meanshift3, double *varval) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  if (meanshift3) memcpy(meanshift3, o->b->probs[0].meanshift, sizeof(double) * 3);
+  if (varval) *varval = o->b->probs[0].varval;
+  return ICTR_OK;
+}

@@ -1,0 +1,686 @@
+// ictr_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the Gauss-Newton photometric tracker.
+//
+// Reference steps (odometer.cpp:257-426, /root/reference) -> kernels:
+//   step 3   project at the reference pose, all levels      k_project_ref      (pose.cpp:307-488)
+//   step 4-6 reference patches + gradients, sd coefficients,
+//            Hessian                                        k_ref_level        (utilities.cpp:115-189, odometer.cpp:268-334,428-472)
+//   step 7-10 project, fetch current patch, residual,
+//            J^T r, solve, pose update, loop condition       k_iter             (utilities.cpp:55-113, odometer.cpp:344-418,509-515)
+//   pyramid  2x2 box + [-1 0 1] gradients + padding          k_pyr_*            (utilities.cpp:14-52)
+//
+// Design: memory-bound gather + rank-1 accumulate, no MFMA. One wave64 owns one 8x8 patch
+// (four 4x4 patches): the 64 lanes ARE the 64 patch pixels, so T/Gx/Gy are read as 256-B coalesced rows, the
+// bilinear taps are 8 x 32-B row segments, and the six J^T r sums live in per-lane registers across all the
+// patches a wave visits -- one shuffle reduction per wave per launch, not per patch. The steepest-descent
+// images of the reference (6 planes + 6 projected planes, re-zeroed every iteration) are never materialised:
+// a patch carries 12 scalar coefficients. The last workgroup of a problem to finish (agent-scope ticket)
+// reduces the per-block partials in a fixed order, solves the 6x6 system and updates the pose, so one
+// launch == one Gauss-Newton iteration and the host never reads anything back inside the loop.
+//
+// Arithmetic parity: compiled with -ffp-contract=off; every expression below keeps the reference's
+// operand order, so patches, projections and coefficients are bit-identical to the CPU path; only the
+// order of the big sums differs.
+#include "ictr_dev.h"
+#include "se3_math.h"
+
+namespace ictr {
+
+// ---------------------------------------------------------------- small device helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// sum over aligned groups of `width` lanes (width = power of two <= 64)
+__device__ __forceinline__ float group_sum(float v, int width) {
+  for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+struct Taps {
+  float w0, w1, w2, w3;
+  int col0, row0;
+};
+
+// utilities.cpp:66-77 : patch-constant bilinear weights, ceil(x+1e-5f) tap selection
+__device__ __forceinline__ Taps make_taps(float mx, float my, int pszd2) {
+  Taps t;
+  const int p0 = (int)ceilf(mx + .00001f);
+  const int p1 = (int)ceilf(my + .00001f);
+  const int p2 = (int)floorf(mx);
+  const int p3 = (int)floorf(my);
+  const float r0 = mx - (float)p2;
+  const float r1 = my - (float)p3;
+  t.w0 = r0 * r1;
+  t.w1 = (1 - r0) * r1;
+  t.w2 = r0 * (1 - r1);
+  t.w3 = (1 - r0) * (1 - r1);
+  t.col0 = p0 + pszd2;
+  t.row0 = p1 + pszd2;
+  return t;
+}
+
+// utilities.cpp:107 : a=(col,row) b=(col-1,row) c=(col,row-1) d=(col-1,row-1)
+__device__ __forceinline__ float tap4(const float *__restrict__ img, int idx, int sw, const Taps &t) {
+  const float a = img[idx], b = img[idx - 1], c = img[idx - sw], d = img[idx - sw - 1];
+  return t.w0 * a + t.w1 * b + t.w2 * c + t.w3 * d;
+}
+
+__device__ __forceinline__ bool in_view(float mx, float my, float swo, float sho) {
+  // odometer.cpp:273-276 rejects (x<0)|(y<0)|(x>swo)|(y>sho); written positively so NaN is "outside"
+  return (mx >= 0.0f) & (my >= 0.0f) & (mx <= swo) & (my <= sho);
+}
+
+// odometer.cpp:313-326 : per-point steepest-descent coefficients; the "1.0 +" terms are f64, narrowed
+__device__ __forceinline__ void sd_coefs(float X, float Y, float Z, float fx, float fy, float *cx, float *cy) {
+  const float zsq = Z * Z;
+  cx[0] = fx / Z;
+  cy[0] = 0.0f;
+  cx[1] = 0.0f;
+  cy[1] = fy / Z;
+  cx[2] = -X / zsq * fx;
+  cy[2] = -Y / zsq * fy;
+  cx[3] = -X * Y / zsq * fx;
+  cy[3] = (float)((-(1.0 + (double)(Y * Y / zsq))) * (double)fy);
+  cx[4] = (float)((1.0 + (double)(X * X / zsq)) * (double)fx);
+  cy[4] = X * Y / zsq * fy;
+  cx[5] = -Y / Z * fx;
+  cy[5] = X / Z * fy;
+}
+
+__device__ __forceinline__ void sd_values(float gx, float gy, const float *cx, const float *cy, float *sd) {
+  sd[0] = gx * cx[0];
+  sd[1] = gy * cy[1];
+#pragma unroll
+  for (int k = 2; k < 6; ++k) sd[k] = gx * cx[k] + gy * cy[k];
+}
+
+// Ticket: returns true in every thread of the LAST workgroup (of `nblocks`) to arrive. Producer side follows
+// cdna_hip_programming.md Guideline 16: stores -> vmcnt(0) -> barrier -> one lane agent-release -> vmcnt(0)
+// -> relaxed agent atomic; the last arriver does one agent acquire before anybody reads the partials.
+__device__ __forceinline__ bool arrive_is_last(unsigned *counter, unsigned nblocks, unsigned *s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (t == nblocks - 1u) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0u;
+}
+
+__device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
+  // odometer.cpp:341-346
+  st.normdp_init = 1e-10f;
+  st.normdp = 1e-10f;
+  st.it = 0;
+  st.active = ((0 < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
+}
+
+// steps 9b + 10 + loop condition, one thread. ws: LDS scratch (>= 36+6 floats, 12 ints).
+__device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, int prob) {
+  float dp[6];
+  lu_solve<6>(st.H, st.b, dp);
+  float p[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    st.dp[k] = dp[k];
+    p[k] = st.p[k] + dp[k];  // pose.cpp:118-123 additive update
+    st.p[k] = p[k];
+  }
+  float G[12];
+  se3_exp<float>(G, p);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) st.G[k] = G[k];
+  // delta_p.lpNorm<1>() : Eigen's unrolled redux tree for 6 coefficients
+  const float nd = (fabsf(dp[0]) + (fabsf(dp[1]) + fabsf(dp[2]))) + (fabsf(dp[3]) + (fabsf(dp[4]) + fabsf(dp[5])));
+  st.normdp = nd;
+  if (st.it == 0) st.normdp_init = nd;
+  if (e.trace.rec != nullptr && prob == 0) {
+    const int c = *e.trace.count;
+    if (c < e.trace.capacity) {
+      ictr_trace_rec &r = e.trace.rec[c];
+      r.level = level;
+      r.iter = st.it;
+      for (int k = 0; k < 36; ++k) r.H[k] = st.H[k];
+      for (int k = 0; k < 6; ++k) {
+        r.b[k] = st.b[k];
+        r.dp[k] = dp[k];
+        r.p[k] = p[k];
+      }
+    }
+    *e.trace.count = c + 1;
+  }
+  st.it += 1;
+  st.total_iters += 1;
+  st.active = ((st.it < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- step 3: projection at the reference pose
+// pose.cpp:400-488 (save rotated, level lv_f) + pose.cpp:307-397 for the other levels (odometer.cpp:251-254).
+// The camera-frame point is level independent, so one pass writes every level.
+struct AllCams {
+  LevelCam lc[16];
+};
+
+__global__ __launch_bounds__(kBlock) void k_project_ref(EngineDev e, AllCams cams) {
+  const int b = blockIdx.y;
+  const ProbState &st = e.st[b];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= st.npts) return;
+  const float *p3 = e.pt3d + (size_t)b * 3 * e.M;
+  float *p3r = e.pt3d_ref + (size_t)b * 3 * e.M;
+  const float X = p3[i], Y = p3[i + e.M], Z = p3[i + 2 * e.M];
+  const float tx = st.G[0] * X + st.G[1] * Y + st.G[2] * Z + st.G[3];
+  const float ty = st.G[4] * X + st.G[5] * Y + st.G[6] * Z + st.G[7];
+  const float tz = st.G[8] * X + st.G[9] * Y + st.G[10] * Z + st.G[11];
+  p3r[i] = tx;
+  p3r[i + e.M] = ty;
+  p3r[i + 2 * e.M] = tz;
+  for (int l = e.lv_l; l <= e.lv_f; ++l) {
+    float *p2 = e.pt2d + ((size_t)b * e.nlev + l) * 2 * e.M;
+    p2[i] = (tx / tz) * cams.lc[l].fx + cams.lc[l].cx;
+    p2[i + e.M] = (ty / tz) * cams.lc[l].fy + cams.lc[l].cy;
+  }
+}
+
+// PoseClass::project_pt / project_pt_save_rotated on caller buffers (device copies), SoA stride M
+__global__ __launch_bounds__(kBlock) void k_project_generic(const float *__restrict__ pt3d, float *pt3d_rot,
+                                                            float *pt2d, int n, int M, const float *__restrict__ G,
+                                                            LevelCam lc) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float X = pt3d[i], Y = pt3d[i + M], Z = pt3d[i + 2 * M];
+  const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
+  const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
+  const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
+  if (pt3d_rot) {
+    pt3d_rot[i] = tx;
+    pt3d_rot[i + M] = ty;
+    pt3d_rot[i + 2 * M] = tz;
+  }
+  pt2d[i] = (tx / tz) * lc.fx + lc.cx;
+  pt2d[i + M] = (ty / tz) * lc.fy + lc.cy;
+}
+
+// ---------------------------------------------------------------- steps 4-6: per level setup
+// PT = compile-time patch size (8 or 4), or 0 = run-time e.P (any size; a wave loops over the pixels).
+template <int PT>
+__global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, int level) {
+  __shared__ float sW[kWaves][kPartHStride];
+  __shared__ double sRed[kBlock / 32][32];
+  __shared__ unsigned sFlag;
+  const int b = blockIdx.y;
+  ProbState &st = e.st[b];
+  const int npts = st.npts;
+  const int P = PT ? PT : e.P;
+  const int n = P * P;
+  const int pszd2 = P / 2;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *pt2d = e.pt2d + ((size_t)b * e.nlev + level) * 2 * M;
+  const float *p3r = e.pt3d_ref + (size_t)b * 3 * M;
+  float *T = e.T + (size_t)b * M * n;
+  float *Gx = e.Gx + (size_t)b * M * n;
+  float *Gy = e.Gy + (size_t)b * M * n;
+  float *coefb = e.coef + (size_t)b * M * kCoefStride;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ppw = (n <= 64 && (64 % n) == 0) ? 64 / n : 1;  // patches per wave
+  const int sub = ppw > 1 ? lane / n : 0;
+  const int q0 = ppw > 1 ? lane % n : lane;
+  const int qstride = ppw > 1 ? n : 64;
+  const int gwidth = ppw > 1 ? n : 64;
+
+  float acc[kHUnique];
+#pragma unroll
+  for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
+
+  const int nw = gridDim.x * kWaves;
+  for (int g = blockIdx.x * kWaves + wave; g * ppw < npts; g += nw) {
+    const int i = g * ppw + sub;
+    const bool valid = i < npts;
+    const float mx = valid ? pt2d[i] : -1.0f;
+    const float my = valid ? pt2d[i + M] : -1.0f;
+    const bool vis = valid && in_view(mx, my, lc.swo, lc.sho);
+    float cx[6], cy[6];
+    if (vis) {
+      sd_coefs(p3r[i], p3r[i + M], p3r[i + 2 * M], lc.fx, lc.fy, cx, cy);
+      if (q0 == 0) {
+        float *c = coefb + (size_t)i * kCoefStride;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          c[k] = cx[k];
+          c[6 + k] = cy[k];
+        }
+      }
+    } else if (valid) {  // out of the reference view at this level: keep the stale coefficients (quirk, odometer.cpp:304)
+      const float *c = coefb + (size_t)i * kCoefStride;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        cx[k] = c[k];
+        cy[k] = c[6 + k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cx[k] = cy[k] = 0.0f;
+    }
+    const Taps tp = make_taps(vis ? mx : 0.0f, vis ? my : 0.0f, pszd2);
+    const int base = (tp.row0)*lc.sw + tp.col0;
+
+    float mean = 0.0f;
+    if (e.dopatchnorm) {  // utilities.cpp:187-188 : intensity patch only
+      float s = 0.0f;
+      for (int q = q0; q < n; q += qstride)
+        if (vis) s += tap4(pl.ref, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
+      s = group_sum(s, gwidth);
+      mean = s / (float)n;
+    }
+    for (int q = q0; q < n; q += qstride) {
+      float gx = 0.0f, gy = 0.0f;
+      const size_t o = (size_t)i * n + q;
+      if (vis) {
+        const int idx = base + (q / P) * lc.sw + (q % P);
+        float t = tap4(pl.ref, idx, lc.sw, tp);
+        if (e.dopatchnorm) t -= mean;
+        gx = tap4(pl.dx, idx, lc.sw, tp);
+        gy = tap4(pl.dy, idx, lc.sw, tp);
+        T[o] = t;
+        Gx[o] = gx;
+        Gy[o] = gy;
+      } else if (valid) {
+        gx = Gx[o];
+        gy = Gy[o];
+      }
+      float sd[6];
+      sd_values(gx, gy, cx, cy, sd);
+      int jk = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int k = j; k < 6; ++k) acc[jk++] += sd[j] * sd[k];
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < kHUnique; ++j) {
+    const float v = wave_sum(acc[j]);
+    if (lane == 0) sW[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kHUnique) {
+    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+    e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
+  }
+  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
+
+  // last workgroup of this problem: fixed-order reduction of the block partials (f64), publish H.
+  // 8 slices x 32 components: thread (slice, j) sums blocks slice, slice+8, ...; then 8 slices in order.
+  {
+    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double s = 0.0;
+    const float *ph = e.partH + (size_t)b * gridDim.x * kPartHStride + j;
+    if (j < kHUnique)
+      for (unsigned k = sl; k < gridDim.x; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
+    sRed[sl][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kHUnique) {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBlock / 32; ++sl) s += sRed[sl][threadIdx.x];
+    sW[0][threadIdx.x] = (float)s;
+  }
+  __syncthreads();
+  if (e.sharded) {
+    if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sW[0][threadIdx.x];
+  } else if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    st.H[threadIdx.x] = sW[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+  }
+  if (threadIdx.x == 0) {
+    st.arrive = 0u;
+    if (!e.sharded) level_reset(st, e);
+  }
+}
+
+// sharded mode: adopt the all-reduced H (red[b][0..20]) and reset the iteration state
+__global__ void k_level_finish(EngineDev e) {
+  const int b = blockIdx.x;
+  ProbState &st = e.st[b];
+  if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    st.H[threadIdx.x] = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+  }
+  if (threadIdx.x == 0) level_reset(st, e);
+}
+
+// ---------------------------------------------------------------- steps 7-10: one Gauss-Newton iteration
+// LDSWIN: stage the (P+1)x(P+1) current-frame window of each patch through wave-private LDS (PT==8 only).
+template <int PT, bool LDSWIN>
+__global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int level) {
+  __shared__ float sW[kWaves][kPartBStride];
+  __shared__ double sRed[kBlock / 8][8];
+  __shared__ float sWin[LDSWIN ? kWaves : 1][LDSWIN ? 96 : 1];
+  __shared__ unsigned sFlag;
+  const int b = blockIdx.y;
+  ProbState &st = e.st[b];
+  if (!st.active) return;  // loop condition of odometer.cpp:344-346, decided by the previous launch
+  const int npts = st.npts;
+  const int P = PT ? PT : e.P;
+  const int n = P * P;
+  const int pszd2 = P / 2;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
+  const float *__restrict__ T = e.T + (size_t)b * M * n;
+  const float *__restrict__ Gx = e.Gx + (size_t)b * M * n;
+  const float *__restrict__ Gy = e.Gy + (size_t)b * M * n;
+  const float *__restrict__ coefb = e.coef + (size_t)b * M * kCoefStride;
+  const float *__restrict__ cur = pl.cur;
+
+  float G[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = st.G[k];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ppw = (n <= 64 && (64 % n) == 0) ? 64 / n : 1;
+  const int sub = ppw > 1 ? lane / n : 0;
+  const int q0 = ppw > 1 ? lane % n : lane;
+  const int qstride = ppw > 1 ? n : 64;
+  const int gwidth = ppw > 1 ? n : 64;
+
+  float acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+
+  const int nw = gridDim.x * kWaves;
+  for (int g = blockIdx.x * kWaves + wave; g * ppw < npts; g += nw) {
+    const int i = g * ppw + sub;
+    const bool valid = i < npts;
+    // step 7 (pose.cpp:384-391)
+    const float X = valid ? p3[i] : 0.0f, Y = valid ? p3[i + M] : 0.0f, Z = valid ? p3[i + 2 * M] : 1.0f;
+    const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
+    const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
+    const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
+    const float mx = (tx / tz) * lc.fx + lc.cx;
+    const float my = (ty / tz) * lc.fy + lc.cy;
+    const bool vis = valid && in_view(mx, my, lc.swo, lc.sho);  // ind_new (odometer.cpp:369-377)
+    float cx[6], cy[6];
+    {
+      const float4 *c4 = reinterpret_cast<const float4 *>(coefb + (size_t)(valid ? i : 0) * kCoefStride);
+      const float4 c0 = c4[0], c1 = c4[1], c2 = c4[2];
+      cx[0] = c0.x; cx[1] = c0.y; cx[2] = c0.z; cx[3] = c0.w; cx[4] = c1.x; cx[5] = c1.y;
+      cy[0] = c1.z; cy[1] = c1.w; cy[2] = c2.x; cy[3] = c2.y; cy[4] = c2.z; cy[5] = c2.w;
+    }
+    const Taps tp = make_taps(vis ? mx : 0.0f, vis ? my : 0.0f, pszd2);
+    const int base = tp.row0 * lc.sw + tp.col0;
+
+    if constexpr (LDSWIN && PT == 8) {
+      // 9x9 window, origin (col0-1,row0-1): 81 texels by 64 lanes in two coalesced passes (9 row segments of 36 B)
+      float *win = sWin[wave];
+      const int org = base - lc.sw - 1;
+      {
+        const int t0 = lane, t1 = lane + 64;
+        const float v0 = vis ? cur[org + (t0 / 9) * lc.sw + (t0 % 9)] : 0.0f;
+        float v1 = 0.0f;
+        if (vis && t1 < 81) v1 = cur[org + (t1 / 9) * lc.sw + (t1 % 9)];
+        win[t0] = v0;
+        if (t1 < 96) win[t1] = v1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int py = lane >> 3, px = lane & 7;
+      const float a = win[(py + 1) * 9 + px + 1], bb = win[(py + 1) * 9 + px], c = win[py * 9 + px + 1],
+                  d = win[py * 9 + px];
+      float inew = tp.w0 * a + tp.w1 * bb + tp.w2 * c + tp.w3 * d;
+      __builtin_amdgcn_wave_barrier();
+      if (e.dopatchnorm) {
+        const float s = wave_sum(vis ? inew : 0.0f);
+        inew -= s / (float)n;
+      }
+      if (vis) {
+        const size_t o = (size_t)i * 64 + lane;
+        const float r = T[o] - inew;
+        float sd[6];
+        sd_values(Gx[o], Gy[o], cx, cy, sd);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += sd[k] * r;
+      }
+    } else {
+      float mean = 0.0f;
+      if (e.dopatchnorm) {  // utilities.cpp:111-112
+        float s = 0.0f;
+        for (int q = q0; q < n; q += qstride)
+          if (vis) s += tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
+        s = group_sum(s, gwidth);
+        mean = s / (float)n;
+      }
+      for (int q = q0; q < n; q += qstride) {
+        if (vis) {
+          const size_t o = (size_t)i * n + q;
+          float inew = tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
+          if (e.dopatchnorm) inew -= mean;
+          const float r = T[o] - inew;  // pdiff (odometer.cpp:381)
+          float sd[6];
+          sd_values(Gx[o], Gy[o], cx, cy, sd);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[k] += sd[k] * r;  // sd*_proj summed (odometer.cpp:386-404)
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) sW[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+    e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
+  }
+  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
+
+  // fixed-order reduction of the block partials in f64: 32 slices x 8 components, then the slices in order
+  {
+    const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    double s = 0.0;
+    const float *pb = e.partb + (size_t)b * gridDim.x * kPartBStride + j;
+    if (j < 6)
+      for (unsigned k = sl; k < gridDim.x; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
+    sRed[sl][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBlock / 8; ++sl) s += sRed[sl][threadIdx.x];
+    if (e.sharded)
+      e.red[(size_t)b * kRedStride + kHUnique + threadIdx.x] = (float)s;
+    else
+      st.b[threadIdx.x] = (float)s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.arrive = 0u;
+    if (!e.sharded) solve_and_update(st, e, level, b);
+  }
+}
+
+// sharded mode: steps 9b-10 on the all-reduced b (red[b][21..26]); every rank does the same arithmetic
+__global__ void k_iter_finish(EngineDev e, int level) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= e.B) return;
+  ProbState &st = e.st[b];
+  if (!st.active) return;
+  for (int k = 0; k < 6; ++k) st.b[k] = e.red[(size_t)b * kRedStride + kHUnique + k];
+  solve_and_update(st, e, level, b);
+}
+
+// ---------------------------------------------------------------- util_getPatch(_grad) for callers (NCC scoring etc.)
+__global__ __launch_bounds__(kBlock) void k_getpatch(const float *__restrict__ img, const float *__restrict__ dx,
+                                                     const float *__restrict__ dy, const float *__restrict__ mids,
+                                                     int K, int P, int sw, int dopatchnorm, float *out, float *out_dx,
+                                                     float *out_dy) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n = P * P;
+  for (int i = blockIdx.x * kWaves + wave; i < K; i += gridDim.x * kWaves) {
+    const Taps tp = make_taps(mids[i], mids[i + K], P / 2);
+    const int base = tp.row0 * sw + tp.col0;
+    float s = 0.0f;
+    for (int q = lane; q < n; q += 64) {
+      const int idx = base + (q / P) * sw + (q % P);
+      const float t = tap4(img, idx, sw, tp);
+      out[(size_t)i * n + q] = t;
+      s += t;
+      if (dx) out_dx[(size_t)i * n + q] = tap4(dx, idx, sw, tp);
+      if (dy) out_dy[(size_t)i * n + q] = tap4(dy, idx, sw, tp);
+    }
+    if (dopatchnorm) {
+      const float mean = wave_sum(s) / (float)n;
+      for (int q = lane; q < n; q += 64) out[(size_t)i * n + q] -= mean;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- pyramid (utilities.cpp:14-52)
+// level 0: copy the w x h image into the interior of the padded plane
+__global__ __launch_bounds__(kBlock) void k_pyr_copy(const float *__restrict__ src, float *dst, int w, int h, int pad,
+                                                     int sw) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  if (x < w && y < h) dst[(size_t)(y + pad) * sw + x + pad] = src[(size_t)y * w + x];
+}
+
+// level l from level l-1: cv::resize(.5,.5,INTER_LINEAR) == 2x2 box mean for even sizes; clamped bilinear otherwise
+__global__ __launch_bounds__(kBlock) void k_pyr_down(const float *__restrict__ src, int pw, int ph, int psw,
+                                                     float *dst, int w, int h, int pad, int sw) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float *s = src + (size_t)pad * psw + pad;  // interior origin of the previous level
+  float v;
+  if (pw == 2 * w && ph == 2 * h) {
+    const float *r0 = s + (size_t)(2 * y) * psw + 2 * x;
+    const float *r1 = r0 + psw;
+    v = ((r0[0] + r1[0]) + (r0[1] + r1[1])) * 0.25f;
+  } else {
+    int y0 = 2 * y, y1 = y0 + 1, x0 = 2 * x, x1 = x0 + 1;
+    y0 = min(y0, ph - 1);
+    y1 = min(y1, ph - 1);
+    x0 = min(x0, pw - 1);
+    x1 = min(x1, pw - 1);
+    const float top = s[(size_t)y0 * psw + x0] * 0.5f + s[(size_t)y0 * psw + x1] * 0.5f;
+    const float bot = s[(size_t)y1 * psw + x0] * 0.5f + s[(size_t)y1 * psw + x1] * 0.5f;
+    v = top * 0.5f + bot * 0.5f;
+  }
+  dst[(size_t)(y + pad) * sw + x + pad] = v;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) return -i;
+  if (i >= n) return 2 * n - 2 - i;
+  return i;
+}
+
+// replicate-pad the image in place (border threads read interior, write border) and write both gradient planes:
+// cv::Sobel(ksize=1) = I(x+1)-I(x-1) with reflect-101, then zero padding
+__global__ __launch_bounds__(kBlock) void k_pyr_finish(float *img, float *dx, float *dy, int w, int h, int pad, int sw,
+                                                       int sh, int getgrad) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  if (x >= sw || y >= sh) return;
+  const int ix = x - pad, iy = y - pad;
+  const bool inside = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h);
+  const float *I = img + (size_t)pad * sw + pad;
+  const size_t o = (size_t)y * sw + x;
+  if (!inside) {
+    const int cxx = min(max(ix, 0), w - 1), cyy = min(max(iy, 0), h - 1);
+    img[o] = I[(size_t)cyy * sw + cxx];
+    if (getgrad) {
+      dx[o] = 0.0f;
+      dy[o] = 0.0f;
+    }
+  } else if (getgrad) {
+    dx[o] = I[(size_t)iy * sw + reflect101(ix + 1, w)] - I[(size_t)iy * sw + reflect101(ix - 1, w)];
+    dy[o] = I[(size_t)reflect101(iy + 1, h) * sw + ix] - I[(size_t)reflect101(iy - 1, h) * sw + ix];
+  }
+}
+
+// ---------------------------------------------------------------- host-side launchers
+static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + kWaves - 1) / kWaves); }
+
+void launch_pyr_copy(const float *src, float *dst, int w, int h, int pad, int sw, hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_copy, grid2d(w, h), dim3(kBlock), 0, s, src, dst, w, h, pad, sw);
+}
+void launch_pyr_down(const float *src, int pw, int ph, int psw, float *dst, int w, int h, int pad, int sw,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_down, grid2d(w, h), dim3(kBlock), 0, s, src, pw, ph, psw, dst, w, h, pad, sw);
+}
+void launch_pyr_finish(float *img, float *dx, float *dy, int w, int h, int pad, int sw, int sh, int getgrad,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_finish, grid2d(sw, sh), dim3(kBlock), 0, s, img, dx, dy, w, h, pad, sw, sh, getgrad);
+}
+void launch_getpatch(const float *img, const float *dx, const float *dy, const float *mids, int K, int P, int sw,
+                     int dopatchnorm, float *out, float *out_dx, float *out_dy, hipStream_t s) {
+  int gx = (K + kWaves - 1) / kWaves;
+  if (gx > kMaxGridX) gx = kMaxGridX;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_getpatch, dim3(gx), dim3(kBlock), 0, s, img, dx, dy, mids, K, P, sw, dopatchnorm, out, out_dx,
+                     out_dy);
+}
+void launch_project_generic(const float *pt3d, float *pt3d_rot, float *pt2d, int n, int M, const float *G,
+                            LevelCam lc, hipStream_t s) {
+  hipLaunchKernelGGL(k_project_generic, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pt3d, pt3d_rot, pt2d, n, M,
+                     G, lc);
+}
+void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hipStream_t s) {
+  AllCams ac;
+  for (int l = 0; l < e.nlev && l < 16; ++l) ac.lc[l] = cams[l];
+  hipLaunchKernelGGL(k_project_ref, dim3((maxpts + kBlock - 1) / kBlock, e.B), dim3(kBlock), 0, s, e, ac);
+}
+void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, hipStream_t s) {
+  const dim3 g(gridx, e.B), blk(kBlock);
+  if (e.P == 8)
+    hipLaunchKernelGGL(k_ref_level<8>, g, blk, 0, s, e, lc, level);
+  else if (e.P == 4)
+    hipLaunchKernelGGL(k_ref_level<4>, g, blk, 0, s, e, lc, level);
+  else
+    hipLaunchKernelGGL(k_ref_level<0>, g, blk, 0, s, e, lc, level);
+}
+void launch_level_finish(const EngineDev &e, hipStream_t s) {
+  hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e);
+}
+void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, hipStream_t s) {
+  const dim3 g(gridx, e.B), blk(kBlock);
+  if (e.P == 8) {
+    if (variant & 1)
+      hipLaunchKernelGGL((k_iter<8, true>), g, blk, 0, s, e, lc, level);
+    else
+      hipLaunchKernelGGL((k_iter<8, false>), g, blk, 0, s, e, lc, level);
+  } else if (e.P == 4)
+    hipLaunchKernelGGL((k_iter<4, false>), g, blk, 0, s, e, lc, level);
+  else
+    hipLaunchKernelGGL((k_iter<0, false>), g, blk, 0, s, e, lc, level);
+}
+void launch_iter_finish(const EngineDev &e, int level, hipStream_t s) {
+  hipLaunchKernelGGL(k_iter_finish, dim3((e.B + 63) / 64), dim3(64), 0, s, e, level);
+}
+
+}  // namespace ictr
