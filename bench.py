@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- Gauss-Newton tracking throughput on MI355X (BASELINE.json metric: GN iterations/s and aligned
+Mpix/s on 1920x1080 3-level pyramids).
+
+Workload "R1080p-dense-se3" (default): the reference-faithful tracker (OdometerClass::TrackPose semantics,
+6-DoF SE(3), odometer.cpp:257-426) on 1920x1080 frames with a 3-level pyramid (lv_f=2, lv_l=0), 8x8 patches on
+an 8-px grid that tiles the frame exactly (240 x 135 = 32 400 points => 2 073 600 aligned pixels per GN
+iteration, the pixel count of a full 1080p frame), maxiter=10 with normdp_ratio=0 (fixed iteration count, so
+every launch does full work), donorm=0, dopatchnorm=0. A "step" is one coarse-to-fine tracking (SetPose
+projection + 3 levels x [setup + 10 GN iterations]) of a batch of B independent frame pairs (default 16: each
+pair has its own pyramids and patch buffers, so one GN iteration streams B x 33 MB and cannot live in the 256 MB
+Infinity Cache). Inputs (pyramids, 3-D points) are resident in HBM before the timed region; the timed region
+ends with the poses on the host.
+
+  value        = aligned pixels / s  (pixels entering the residual, all levels, all problems, all ranks) in Mpix/s
+  roofline     = the level-0 GN-iteration kernel: algorithmic bytes (16 B per patch pixel: T, Gx, Gy, one
+                 current-frame texel) per launch / mean launch duration, measured with HIP events
+                 on the kernel's stream over the timed steps, vs 8 TB/s HBM3E.
+  cpu_baseline = the oracle (C restatement of the reference, one thread, -O3 -msse4 -mavx) timed on the same
+                 workload for one frame pair (a bounded sample), on this host's cores.
+
+N > 1 (torchrun, one rank per GPU): the points of every frame pair are sharded over the ranks (each rank owns
+32 400 points per pair => weak scaling), frames are replicated, and the ranks all-reduce 21 floats of H per level
+and 6 floats of b per GN iteration per pair over RCCL (invcompcamtrack_amd/dist.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="independent frame pairs per step (per rank)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--levels", type=int, default=3)
+    ap.add_argument("--psz", type=int, default=8)
+    ap.add_argument("--maxiter", type=int, default=10)
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (bit0: LDS-staged current-frame window)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
+    return ap.parse_args()
+
+
+def build_inputs(args, rank, world):
+    """Synthetic frames + points. Two distinct scenes are rendered; the B problems alternate between them with
+    their own copies of the pyramids (own HBM), own start pose and own jittered point grid."""
+    import invcompcamtrack_amd as ic
+    from invcompcamtrack_amd import synth
+    w, h, P = args.width, args.height, args.psz
+    lv_f = args.levels - 1
+    scenes = []
+    for s in range(2):
+        scenes.append(synth.make_scene(w, h, grid_step=P, margin=P / 2.0, jitter=0.35, seed=100 + s,
+                                       tex_seed=1234 + s,
+                                       dp_gt=np.array([0.02, -0.015, 0.03, 0.003, -0.002, 0.004]) * (1 + 0.5 * s)))
+    n_pts = scenes[0]["pts3d"].shape[1]
+    op = ic.optparam(lv_f, 0, P, args.maxiter, 0.0, 0, 0, n_pts)
+    cam = ic.CamClass(lv_f + 1, scenes[0]["fc"], scenes[0]["cc"], scenes[0]["wh"], P)
+    batch = ic.TrackBatch(cam, op, args.batch)
+    pyrs = []
+    rng = np.random.default_rng(7 + rank)
+    for b in range(args.batch):
+        sc = scenes[b % 2]
+        pa = ic.Pyramid(sc["img_a"], lv_f, P)
+        pb = ic.Pyramid(sc["img_b"], lv_f, P)
+        pyrs.append((pa, pb))
+        pts = sc["pts3d"].copy()
+        if world > 1 or b >= 2:  # every rank / problem owns a different jittered sample of the same plane
+            pts = pts + rng.normal(0, 1e-3, pts.shape) * np.array([[1.0], [1.0], [0.0]])
+        batch.Set3Dpoints(b, np.ascontiguousarray(pts))
+    return dict(ic=ic, op=op, cam=cam, batch=batch, pyrs=pyrs, scenes=scenes, n_pts=n_pts)
+
+
+def cpu_baseline(args, scene, n_pts):
+    """Oracle (port of the reference's CPU path) on one frame pair of the same workload, single thread."""
+    from oracle import oracle as O
+    lv_f, P = args.levels - 1, args.psz
+    op = O.make_op(lv_f, 0, P, args.maxiter, 0.0, 0, 0, n_pts)
+    pa, pb = O.Pyramid(scene["img_a"], lv_f, P), O.Pyramid(scene["img_b"], lv_f, P)
+    tr = O.Tracker(op, scene["fc"], scene["cc"], scene["wh"])
+    pix_per_run = args.levels * args.maxiter * n_pts * P * P
+    runs, t_used = 0, 0.0
+    t_end = time.perf_counter() + args.cpu_seconds
+    while True:
+        pts = scene["pts3d"].copy()
+        t0 = time.perf_counter()
+        tr.set3dpoints(pts)
+        tr.setpose(scene["p_a"], pa, pb)
+        tr.trackpose()
+        t_used += time.perf_counter() - t0
+        runs += 1
+        if time.perf_counter() > t_end or runs >= 1000:
+            break
+    return {"value": pix_per_run * runs / t_used / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "gn_iters_per_s": args.levels * args.maxiter * runs / t_used,
+            "sample": f"{runs} full trackings of one {args.width}x{args.height} frame pair ({n_pts} points, "
+                      f"{args.levels} levels x {args.maxiter} iterations), {t_used:.1f} s; oracle/libictr_oracle.so "
+                      f"(C restatement of the reference, gcc -O3 -msse4 -mavx, 1 thread of {os.cpu_count()})"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    from invcompcamtrack_amd import _lib
+    _lib.check(_lib.load().ictr_set_device(local_rank if world > 1 else 0))
+
+    inp = build_inputs(args, rank, world)
+    batch, op, pyrs, scenes = inp["batch"], inp["op"], inp["pyrs"], inp["scenes"]
+    B, P, n_pts = args.batch, args.psz, inp["n_pts"]
+    batch.set_variant(args.variant)
+    tracker = None
+    if world > 1:
+        from invcompcamtrack_amd.dist import ShardedTracker
+        tracker = ShardedTracker(batch)
+    elif not args.no_events:
+        batch.set_timing(True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        for b in range(B):
+            pa, pb = pyrs[b]
+            batch.SetPose(b, scenes[b % 2]["p_a"], pa, pb)
+        if tracker is not None:
+            tracker.track()
+        else:
+            batch.track_async()
+        return batch.poses()  # waits for the stream, poses on the host
+
+    for _ in range(args.warmup):
+        poses = step()
+    ev_setup = np.zeros(args.levels)
+    ev_iters = np.zeros(args.levels)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        poses = step()
+        if tracker is None and not args.no_events:
+            a, b_ = batch.level_times()
+            ev_setup += a
+            ev_iters += b_
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    iters_per_step = args.levels * args.maxiter * B           # per rank
+    pix_per_iter = n_pts * P * P                               # per problem per rank
+    total_pix = iters_per_step * pix_per_iter * args.steps * world
+    err = float(max(np.abs(poses[b] - scenes[b % 2]["p_b"]).max() for b in range(B)))
+
+    if rank == 0:
+        out = {
+            "metric": "aligned_Mpix_per_s (IC-GN, 1920x1080, 3-level pyramid)",
+            "value": total_pix / dt / 1e6,
+            "unit": "Mpix/s",
+            "gn_iters_per_s": iters_per_step * args.steps * world / dt,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "R1080p-dense-se3: reference-faithful 6-DoF SE(3) tracker, "
+                                   f"{args.width}x{args.height}, {args.levels}-level pyramid, {n_pts} 8x8 patches "
+                                   "tiling the frame, maxiter 10 fixed",
+                       "frame_pairs_per_step_per_gpu": B, "points_per_pair_per_gpu": n_pts, "psz": P,
+                       "levels": args.levels, "maxiter": args.maxiter, "normdp_ratio": 0.0,
+                       "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
+                       "parallelism": "single GPU" if world == 1 else f"points sharded x{world}, RCCL all-reduce of "
+                                                                      "H (21 f32/level) and b (6 f32/iteration)"},
+            "pose_err_vs_ground_truth": err,
+        }
+        if tracker is None and not args.no_events:
+            lv0 = ev_iters[0] / (args.steps * args.maxiter) * 1e-3  # s per level-0 launch (incl. launch gaps)
+            alg = 16.0 * pix_per_iter * B
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("batch") == B and tj.get("points") == n_pts and tj.get("variant") == args.variant:
+                        traffic = tj.get("hbm_bytes_per_launch_level0")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": alg / lv0 / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": alg / lv0 / 1e9 / 8000.0, "traffic": traffic,
+                               "kernel": "k_iter<8> at pyramid level 0",
+                               "algorithmic_bytes_per_launch": alg, "us_per_launch": lv0 * 1e6,
+                               "per_level_us_per_launch": [float(x) / (args.steps * args.maxiter) * 1e3
+                                                           for x in ev_iters],
+                               "per_level_setup_us": [float(x) / args.steps * 1e3 for x in ev_setup]}
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, scenes[0], n_pts)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,11 @@ int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ictr_optparam
 void ictr_batch_destroy(ictr_batch *b);
 int ictr_batch_set_stream(ictr_batch *b, void *hip_stream);
 int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in);
+/* same, with the cloud normalisation supplied by the caller (sharded runs: every rank must use the mean /
+ * mean-squared-radius of ALL points, not of its own slice). Ignored unless op->donorm. */
+int ictr_batch_set3dpoints_norm(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in,
+                                const double *meanshift3, double varval);
+int ictr_batch_get_norm(const ictr_batch *b, int64_t problem, double *meanshift3, double *varval);
 int ictr_batch_setpose(ictr_batch *b, int64_t problem, const double *p_in, const ictr_pyramid *pyr_ref,
                        const ictr_pyramid *pyr_new);
 /* enqueue SetPose's projection + the whole coarse-to-fine loop for every problem; asynchronous */
@@ -187,6 +192,11 @@ int ictr_batch_get_poses(ictr_batch *b, double *p_out);
 int ictr_batch_get_iterations(ictr_batch *b, int *iters);
 int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out /* 2*M */);
 int ictr_batch_set_variant(ictr_batch *b, int variant);
+/* HIP-event timing on the batch's own stream: when enabled, ictr_batch_track_async brackets, per level, the
+ * setup kernel (steps 4-6) and the block of maxiter iteration launches (steps 7-10) with events.
+ * After the track has completed: ms_setup[l], ms_iters[l] for l in 0..lv_f (0 for levels not run). */
+int ictr_batch_set_timing(ictr_batch *b, int enable);
+int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters);
 
 /* ---- distributed (points sharded over ranks): split phases so the caller can all-reduce ----
  * The normal-equation block lives in a caller-visible device buffer: per problem 21 floats of H
@@ -194,6 +204,8 @@ int ictr_batch_set_variant(ictr_batch *b, int variant);
  * accumulate kernels leave rank-local sums there and the *_finish kernels consume the reduced values. */
 int ictr_batch_enable_sharding(ictr_batch *b, int enable);
 float *ictr_batch_reduction_buffer(ictr_batch *b); /* device pointer, nproblems*27 floats */
+/* use a caller-owned device buffer (e.g. a torch tensor handed to torch.distributed) instead; NULL = internal */
+int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr);
 int ictr_batch_begin(ictr_batch *b);                  /* SetPose projection, all problems */
 int ictr_batch_level_accumulate(ictr_batch *b, int level);  /* steps 4-6 -> local H in red[] */
 int ictr_batch_level_finish(ictr_batch *b, int level);      /* adopt (reduced) H, reset iteration state */

@@ -101,12 +101,17 @@ SIGNATURES = {
     "ictr_batch_destroy": (None, [VP]),
     "ictr_batch_set_stream": (C.c_int, [VP, VP]),
     "ictr_batch_set3dpoints": (C.c_int, [VP, I64, DP, I64]),
+    "ictr_batch_set3dpoints_norm": (C.c_int, [VP, I64, DP, I64, DP, C.c_double]),
+    "ictr_batch_get_norm": (C.c_int, [VP, I64, DP, DP]),
     "ictr_batch_setpose": (C.c_int, [VP, I64, DP, VP, VP]),
     "ictr_batch_track_async": (C.c_int, [VP]),
     "ictr_batch_get_poses": (C.c_int, [VP, DP]),
     "ictr_batch_get_iterations": (C.c_int, [VP, IP]),
     "ictr_batch_get2dpoints": (C.c_int, [VP, I64, FP]),
     "ictr_batch_set_variant": (C.c_int, [VP, C.c_int]),
+    "ictr_batch_set_timing": (C.c_int, [VP, C.c_int]),
+    "ictr_batch_get_level_times": (C.c_int, [VP, FP, FP]),
+    "ictr_batch_set_reduction_buffer": (C.c_int, [VP, VP]),
     "ictr_batch_enable_sharding": (C.c_int, [VP, C.c_int]),
     "ictr_batch_reduction_buffer": (VP, [VP]),
     "ictr_batch_begin": (C.c_int, [VP]),
@@ -119,6 +124,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One process must hold ONE HIP/HSA runtime. PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's) and load it by file name, so if our library pulled in the system runtime first, a later
+    `import torch` would bring up a second one and find no GPU. When torch is installed we therefore map its
+    bundled runtime first (without importing torch); libictr_hip.so's NEEDED libamdhip64.so.7 then resolves to it
+    by SONAME. ICTR_SYSTEM_HIP=1 keeps the system runtime (torch must then not be used in the process)."""
+    if os.environ.get("ICTR_SYSTEM_HIP") == "1":
+        return None
+    import sys
+    tlib = None
+    if "torch" in sys.modules:
+        tlib = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "libamdhip64.so")
+    else:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            tlib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if tlib and os.path.exists(tlib):
+        try:
+            return C.CDLL(tlib, mode=C.RTLD_GLOBAL)
+        except OSError:
+            return None
+    return None
+
+
 def load():
     """Load libictr_hip.so and declare every signature. Raises IctrError when the library is absent."""
     global _lib
@@ -127,6 +157,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise IctrError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 missing

@@ -516,10 +516,17 @@ struct ictr_batch {
   std::vector<PlaneSet> h_planes;
   std::vector<float> h_pt2d;  // Get2DPoints mirror of problem 0 (or scratch)
   std::vector<float> h_stage;
+  // optional HIP-event timing (bench.py): per level e0 -> setup kernel -> e1 -> iteration launches -> e2
+  bool timing = false;
+  std::vector<hipEvent_t> ev;  // 3 per level
+  std::vector<char> ev_used;
+  float *d_red_own = nullptr;
 };
 
 static void batch_free(ictr_batch *b) {
   if (!b) return;
+  for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
                   (void *)b->d_st, (void *)b->d_planes, (void *)b->d_trace, (void *)b->d_trace_count})
@@ -613,6 +620,7 @@ extern "C" int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ic
     batch_free(b);
     return fail(ICTR_ERR_HIP, "batch_create: device allocation failed: %s", hipGetErrorString(e));
   }
+  b->d_red_own = b->d_red;
   b->probs.resize(B);
   b->h_st.resize(B);
   b->h_planes.resize(B * L);
@@ -633,8 +641,10 @@ extern "C" int ictr_batch_set_variant(ictr_batch *b, int variant) {
   return ICTR_OK;
 }
 
-// odometer.cpp:171-239 (ResetOdometer + normalisation + f64->f32 SoA)
-extern "C" int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in) {
+// odometer.cpp:171-239 (ResetOdometer + normalisation + f64->f32 SoA).
+// given_ms/given_var: normalisation computed elsewhere (sharded runs need the GLOBAL mean / variance).
+static int set3dpoints_impl(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in, const double *given_ms,
+                            double given_var) {
   if (!b || problem < 0 || problem >= b->B || nopoints_in < 0 || (nopoints_in > 0 && !pt_in))
     return fail(ICTR_ERR_INVALID, "set3dpoints: bad arguments");
   ProbHost &ph = b->probs[problem];
@@ -654,12 +664,16 @@ extern "C" int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt
   float *s = b->h_stage.data();
   if (b->op->donorm) {
     const double nd = (double)np;
-    for (int i = 0; i < np; ++i) ph.meanshift[0] += p1[i];
-    for (int i = 0; i < np; ++i) ph.meanshift[1] += p2[i];
-    for (int i = 0; i < np; ++i) ph.meanshift[2] += p3[i];
-    ph.meanshift[0] /= nd;
-    ph.meanshift[1] /= nd;
-    ph.meanshift[2] /= nd;
+    if (given_ms) {
+      memcpy(ph.meanshift, given_ms, sizeof(double) * 3);
+    } else {
+      for (int i = 0; i < np; ++i) ph.meanshift[0] += p1[i];
+      for (int i = 0; i < np; ++i) ph.meanshift[1] += p2[i];
+      for (int i = 0; i < np; ++i) ph.meanshift[2] += p3[i];
+      ph.meanshift[0] /= nd;
+      ph.meanshift[1] /= nd;
+      ph.meanshift[2] /= nd;
+    }
     for (int i = 0; i < np; ++i) {  // writes back into the caller's array, like odometer.cpp:207-212
       p1[i] -= ph.meanshift[0];
       p2[i] -= ph.meanshift[1];
@@ -667,6 +681,7 @@ extern "C" int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt
       ph.varval += p1[i] * p1[i] + p2[i] * p2[i] + p3[i] * p3[i];
     }
     ph.varval /= nd;  // mean squared radius (no sqrt), odometer.cpp:214
+    if (given_ms) ph.varval = given_var;
     for (int i = 0; i < np; ++i) {
       s[i] = (float)(p1[i] / ph.varval);
       s[i + M] = (float)(p2[i] / ph.varval);
@@ -681,6 +696,20 @@ extern "C" int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt
   }
   HIPCHK(hipMemcpyAsync(b->d_pt3d + problem * 3 * M, s, sizeof(float) * 3 * M, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));  // h_stage is reused by the next call
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_set3dpoints(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in) {
+  return set3dpoints_impl(b, problem, pt_in, nopoints_in, nullptr, 0.0);
+}
+extern "C" int ictr_batch_set3dpoints_norm(ictr_batch *b, int64_t problem, double *pt_in, int64_t nopoints_in,
+                                           const double *meanshift3, double varval) {
+  if (!meanshift3) return fail(ICTR_ERR_INVALID, "set3dpoints_norm: meanshift is NULL");
+  return set3dpoints_impl(b, problem, pt_in, nopoints_in, meanshift3, varval);
+}
+extern "C" int ictr_batch_get_norm(const ictr_batch *b, int64_t problem, double *meanshift3, double *varval) {
+  if (!b || problem < 0 || problem >= b->B) return fail(ICTR_ERR_INVALID, "get_norm: bad arguments");
+  if (meanshift3) memcpy(meanshift3, b->probs[problem].meanshift, sizeof(double) * 3);
+  if (varval) *varval = b->probs[problem].varval;
   return ICTR_OK;
 }
 
@@ -784,17 +813,56 @@ extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
   return ICTR_OK;
 }
 
+static int enqueue_levels(ictr_batch *b) {
+  const EngineDev e = engine_dev(b);
+  if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
+  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
+    const LevelCam lc = level_cam(b->cam, sl);
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], b->stream));
+    launch_ref_level(e, lc, sl, b->gridx, b->stream);
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], b->stream));
+    for (int it = 0; it < b->op->maxiter; ++it) launch_iter(e, lc, sl, b->gridx, b->variant, b->stream);
+    if (b->timing) {
+      HIPCHK(hipEventRecord(b->ev[3 * sl + 2], b->stream));
+      b->ev_used[sl] = 1;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+
 extern "C" int ictr_batch_track_async(ictr_batch *b) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   if (b->sharded) return fail(ICTR_ERR_STATE, "sharded batches are driven phase by phase (see ictr.h)");
   if (int rc = ictr_batch_begin(b)) return rc;
-  const EngineDev e = engine_dev(b);
-  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
-    const LevelCam lc = level_cam(b->cam, sl);
-    launch_ref_level(e, lc, sl, b->gridx, b->stream);
-    for (int it = 0; it < b->op->maxiter; ++it) launch_iter(e, lc, sl, b->gridx, b->variant, b->stream);
+  return enqueue_levels(b);
+}
+
+extern "C" int ictr_batch_set_timing(ictr_batch *b, int enable) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (enable && b->ev.empty()) {
+    b->ev.resize(3 * b->nlev);
+    b->ev_used.assign(b->nlev, 0);
+    for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
   }
-  HIPCHK(hipGetLastError());
+  b->timing = enable != 0;
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters) {
+  if (!b || !ms_setup || !ms_iters) return fail(ICTR_ERR_INVALID, "get_level_times: NULL argument");
+  if (b->ev.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int l = 0; l < b->nlev; ++l) {
+    ms_setup[l] = ms_iters[l] = 0.0f;
+    if (!b->ev_used[l]) continue;
+    HIPCHK(hipEventElapsedTime(&ms_setup[l], b->ev[3 * l + 0], b->ev[3 * l + 1]));
+    HIPCHK(hipEventElapsedTime(&ms_iters[l], b->ev[3 * l + 1], b->ev[3 * l + 2]));
+  }
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  b->d_red = dev_ptr ? dev_ptr : b->d_red_own;
   return ICTR_OK;
 }
 
@@ -904,13 +972,9 @@ extern "C" int ictr_odometer_trackpose(ictr_odometer *o, double *p_out) {
   if (!b->probs[0].pose_set) return fail(ICTR_ERR_STATE, "TrackPose before SetPose");
   if (!b->projected)
     if (int rc = ictr_batch_begin(b)) return rc;
-  const EngineDev e = engine_dev(b);
-  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
-    const LevelCam lc = level_cam(b->cam, sl);
-    launch_ref_level(e, lc, sl, b->gridx, b->stream);
-    for (int it = 0; it < b->op->maxiter; ++it) launch_iter(e, lc, sl, b->gridx, b->variant, b->stream);
-  }
-  HIPCHK(hipGetLastError());
+  if (int rc = enqueue_levels(b)) return rc;
+  // like the reference, a second TrackPose without SetPose continues from the current pose with the old
+  // reference projections (device state persists)
   if (int rc = batch_fetch_state(b)) return rc;
   memcpy(o->pose->p, b->probs[0].p, sizeof(float) * 6);
   memcpy(o->pose->G, b->probs[0].G, sizeof(float) * 12);

@@ -362,6 +362,9 @@ __global__ void k_level_finish(EngineDev e) {
     const int lo = r < c ? r : c, hi = r < c ? c : r;
     st.H[threadIdx.x] = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
   }
+  __syncthreads();
+  // leave the slot zeroed: the caller may all-reduce the whole buffer again before it is rewritten
+  if (threadIdx.x < kRedStride) e.red[(size_t)b * kRedStride + threadIdx.x] = 0.0f;
   if (threadIdx.x == 0) level_reset(st, e);
 }
 
@@ -527,7 +530,10 @@ __global__ void k_iter_finish(EngineDev e, int level) {
   if (b >= e.B) return;
   ProbState &st = e.st[b];
   if (!st.active) return;
-  for (int k = 0; k < 6; ++k) st.b[k] = e.red[(size_t)b * kRedStride + kHUnique + k];
+  for (int k = 0; k < 6; ++k) {
+    st.b[k] = e.red[(size_t)b * kRedStride + kHUnique + k];
+    e.red[(size_t)b * kRedStride + kHUnique + k] = 0.0f;
+  }
   solve_and_update(st, e, level, b);
 }
 

@@ -1,0 +1,90 @@
+"""Multi-GPU tracking: one process per GPU, points sharded over ranks, RCCL all-reduce of the normal equations.
+
+The reference is single-threaded (no threads, no collectives), so this layer is new. The only
+coupling between points is the sum into one 6x6 / 6x1 system -- ComputeHessian (odometer.cpp:428-455) and
+step 9a (odometer.cpp:399-404) -- so every rank owns a contiguous block of points (SoA slices), frames are
+replicated, and per problem the ranks exchange
+    21 floats of H once per pyramid level,   6 floats of b once per Gauss-Newton iteration
+with ``torch.distributed.all_reduce(SUM)`` (backend "nccl" = RCCL over xGMI). Every rank then runs the same
+solve / pose update on identical bits, so no broadcast is needed and the early-exit test stays in lockstep.
+Nothing is read back to the host inside the loop: the accumulate kernels, the collective and the finish
+kernels are all enqueued on the current torch stream.
+
+For tests without several GPUs, ``staged=True`` moves the 27*B floats through host memory and reduces with
+any backend (gloo); the kernels in between are the real HIP kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RED_STRIDE = 27  # per problem: 21 (upper triangle of H, row-major) + 6 (b); kRedStride in csrc/ictr_dev.h
+
+
+def shard_slices(n_points: int, world: int):
+    """Contiguous, balanced point blocks: rank r owns [lo, hi). Empty shards are allowed."""
+    base, rem = divmod(n_points, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def global_norm(pts_local, group=None, dist=None):
+    """Mean and mean squared radius (odometer.cpp:193-214) of the union of all ranks' points.
+    pts_local: (3, n_local) float64. Two tiny all-reduces (f64)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    acc = torch.tensor([pts_local[0].sum(), pts_local[1].sum(), pts_local[2].sum(), float(pts_local.shape[1])],
+                       dtype=torch.float64)
+    dist.all_reduce(acc, group=group)
+    mean = (acc[:3] / acc[3]).numpy().copy()
+    var = torch.tensor([float(((pts_local - mean[:, None]) ** 2).sum())], dtype=torch.float64)
+    dist.all_reduce(var, group=group)
+    return mean, float(var[0] / acc[3])
+
+
+def run_sharded_levels(engine, op, allreduce):
+    """The coarse-to-fine loop of odometer.cpp:261-420 in its sharded form. ``engine`` exposes
+    begin / level_accumulate / level_finish / iter_accumulate / iter_finish (a TrackBatch, or a test double);
+    ``allreduce()`` sums the engine's reduction buffer over all ranks."""
+    engine.begin()
+    for sl in range(op.lv_f, op.lv_l - 1, -1):
+        engine.level_accumulate(sl)   # steps 4-6 on the local points -> local H
+        allreduce()
+        engine.level_finish(sl)       # adopt the global H, reset the iteration state
+        for _ in range(op.maxiter):   # converged problems skip their work on the device (same decision on every rank)
+            engine.iter_accumulate(sl)  # steps 7-9a on the local points -> local b
+            allreduce()
+            engine.iter_finish(sl)      # steps 9b-10, identical on every rank
+
+
+class ShardedTracker:
+    def __init__(self, batch, group=None, staged=False):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.batch, self.group, self.staged = batch, group, staged
+        batch.enable_sharding(True)
+        self.red = torch.zeros(batch.B * RED_STRIDE, dtype=torch.float32, device="cuda")
+        batch.set_reduction_buffer(self.red.data_ptr())
+        batch.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._host = torch.zeros(batch.B * RED_STRIDE, dtype=torch.float32) if staged else None
+
+    def _allreduce(self):
+        dist = self._dist
+        if self.staged:
+            self._host.copy_(self.red)  # synchronises with the current stream
+            dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
+            self.red.copy_(self._host)
+        else:
+            dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.group)
+
+    def track(self):
+        """Enqueue the whole tracking of all problems; returns without synchronising (unless staged)."""
+        run_sharded_levels(self.batch, self.batch.op, self._allreduce)
+
+    def poses(self):
+        return self.batch.poses()

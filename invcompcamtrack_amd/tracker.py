@@ -336,6 +336,20 @@ class TrackBatch:
         n = pt_in.size // 3 if nopoints_in is None else nopoints_in
         check(_lib.load().ictr_batch_set3dpoints(self._h, problem, dp(pt_in), n))
 
+    def Set3Dpoints_norm(self, problem, pt_in, meanshift, varval, nopoints_in=None):
+        """Set3Dpoints with a caller-supplied (global) normalisation; see dist.sharded_set3dpoints."""
+        if not (isinstance(pt_in, np.ndarray) and pt_in.dtype == np.float64 and pt_in.flags.c_contiguous):
+            raise TypeError("Set3Dpoints needs a C-contiguous float64 array")
+        n = pt_in.size // 3 if nopoints_in is None else nopoints_in
+        ms = f64c(meanshift)
+        check(_lib.load().ictr_batch_set3dpoints_norm(self._h, problem, dp(pt_in), n, dp(ms), float(varval)))
+
+    def norm(self, problem):
+        ms = np.zeros(3)
+        vv = C.c_double()
+        check(_lib.load().ictr_batch_get_norm(self._h, problem, dp(ms), C.byref(vv)))
+        return ms, vv.value
+
     def SetPose(self, problem, p_in, img_ref, img_new):
         p_in = f64c(p_in)
         self._keep[problem] = (img_ref, img_new)
@@ -358,6 +372,19 @@ class TrackBatch:
         out = np.empty(2 * self.op.maxpttrack, np.float32)
         check(_lib.load().ictr_batch_get2dpoints(self._h, problem, fp(out)))
         return out
+
+    def set_timing(self, on=True):
+        check(_lib.load().ictr_batch_set_timing(self._h, int(on)))
+
+    def level_times(self):
+        """(ms_setup[l], ms_iters[l]) of the last completed track, measured with HIP events on the batch's stream."""
+        n = self.op.lv_f + 1
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        check(_lib.load().ictr_batch_get_level_times(self._h, fp(a), fp(b)))
+        return a, b
+
+    def set_reduction_buffer(self, dev_ptr):
+        check(_lib.load().ictr_batch_set_reduction_buffer(self._h, C.c_void_p(dev_ptr or 0)))
 
     # phase-by-phase driving (used by the sharded multi-GPU path, invcompcamtrack_amd/dist.py)
     def enable_sharding(self, on=True):

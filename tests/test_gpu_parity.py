@@ -1,0 +1,358 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on identical seeded inputs.
+
+Bars (stated here, used below):
+  * bit-exact: pyramid planes, projections (all levels), reference patches T/Gx/Gy, sd coefficients, current
+    patches at iteration 0, visibility masks -- everything that is element-wise arithmetic.
+  * sums: H and b (J^T J, J^T r over all patch pixels) agree to 2e-6 relative to their largest entry: the
+    reference sums in f32 in Eigen's unspecified order, the GPU in per-lane f32 + fixed-order f64 tree.
+  * first Gauss-Newton step: |dp_gpu - dp_cpu|_inf <= 2e-3 |dp|_inf (the 6x6 system has condition ~1e4..1e6, so
+    1e-7 relative noise on H,b moves dp by up to 1e-3 relative; both sides carry that noise).
+  * final pose: |p_gpu - p_cpu|_inf <= 1e-4 (BASELINE.json north_star), observed ~1e-6.
+"""
+import numpy as np
+import pytest
+
+import invcompcamtrack_amd as ic
+from parity_util import Pair, rel, scene
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4
+SUM_TOL = 2e-6
+DP_TOL = 2e-3
+
+
+def _check_setup_bit_exact(pr, levels):
+    M, n = pr.M, pr.n
+    for l in levels:
+        g2, o2 = pr.odo.read_buffer(100 + l, 2 * M), pr.otr.pt2d(l)
+        assert np.array_equal(g2[:n], o2[:n]) and np.array_equal(g2[M:M + n], o2[M:M + n]), f"pt2d level {l}"
+    g3, o3 = pr.odo.read_buffer(5, 3 * M), pr.otr.buffer(5, 3 * M)
+    for k in range(3):
+        assert np.array_equal(g3[k * M:k * M + n], o3[k * M:k * M + n]), "pt3d_ref"
+
+
+def _check_patches(pr, exact_T=True):
+    nv, n = pr.op.novals, pr.n
+    for w in (1, 2):
+        assert np.array_equal(pr.odo.read_buffer(w, nv * n), pr.otr.buffer(w, nv * n)), f"patch buffer {w}"
+    gT, oT = pr.odo.read_buffer(0, nv * n), pr.otr.buffer(0, nv * n)
+    if exact_T:
+        assert np.array_equal(gT, oT), "T patches"
+    else:  # dopatchnorm: the patch mean is a 64-term sum in a different order
+        assert np.abs(gT - oT).max() <= 1e-4
+
+
+def _check_trace(pr, check_iters=True):
+    to, tg = pr.otr.trace(), pr.odo.trace()
+    if check_iters:
+        assert [(r["level"], r["iter"]) for r in to] == [(r["level"], r["iter"]) for r in tg]
+    for a, b in zip(to, tg):
+        if (a["level"], a["iter"]) != (b["level"], b["iter"]):
+            break
+        assert rel(a["H"], b["H"]) <= SUM_TOL, ("H", a["level"], a["iter"])
+        # b = J^T r depends on the pose the iteration starts from: b(p + e) ~ b(p) - H e. The two runs start
+        # iteration k from poses that differ by e (accumulated rounding), so the b's may differ by |H| |e| plus
+        # the summation noise.
+        e = np.abs((a["p"] - a["dp"]).astype(np.float64) - (b["p"] - b["dp"]).astype(np.float64))
+        # (norm-wise, factor 4: H is the Gauss-Newton matrix at the reference pose, not the exact Jacobian of b)
+        bound = 4.0 * (np.abs(a["H"]).astype(np.float64) @ (e + 2e-7 * np.abs(a["p"]))).max() \
+            + 1e-5 * np.abs(a["b"]).max()
+        assert np.abs(a["b"].astype(np.float64) - b["b"]).max() <= bound, ("b", a["level"], a["iter"])
+    a, b = to[0], tg[0]
+    assert rel(a["b"], b["b"]) <= SUM_TOL, "b at the very first iteration (bit-identical inputs)"
+    assert np.abs(a["dp"] - b["dp"]).max() <= DP_TOL * np.abs(a["dp"]).max(), "first dp"
+
+
+@pytest.mark.parametrize("args", [
+    (4, 0, 4, 5, 0.01, 0, 0),    # run_odometer_test.m:140
+    (4, 0, 8, 10, 0.01, 1, 1),   # run_odometer_test.m:232
+    (4, 0, 8, 10, 0.01, 1, 0),   # run_ransac_test.m:221 / func_ransac_fitcameras_odom.m
+    (3, 1, 8, 6, 0.0, 0, 0),     # fixed iteration count, lv_l > 0
+    (2, 0, 4, 8, 0.0, 0, 1),
+])
+def test_tracker_matches_oracle_reference_parameter_sets(oracle, args):
+    lv_f, lv_l, psz, maxiter, ratio, donorm, dpn = args
+    sc = scene(640, 368, 257, seed=31 + psz)  # 257: not a multiple of 4 -> maxpttrack padding path
+    pr = Pair(oracle, sc, lv_f, lv_l, psz, maxiter, ratio, donorm, dpn)
+    a, b = pr.set_points()
+    assert np.array_equal(a, b)  # Set3Dpoints mutated both inputs identically (donorm)
+    if donorm:
+        assert not np.array_equal(a, sc["pts3d"])
+        ms_o, v_o = pr.otr.norm()
+        ms_g, v_g = pr.odo.norm()
+        assert np.array_equal(ms_o, ms_g) and v_o == v_g
+    pr.set_pose()
+    assert np.array_equal(pr.odo.Get2DPoints()[:pr.n], pr.otr.pt2d(lv_l)[:pr.n])
+    _check_setup_bit_exact(pr, range(lv_l, lv_f + 1))
+    po, pg = pr.track()
+    _check_patches(pr, exact_T=not dpn)
+    _check_trace(pr)
+    assert np.abs(po - pg).max() <= POSE_TOL
+    assert np.abs(pg - sc["p_b"]).max() < 2e-3  # and it is the right answer
+
+
+@pytest.mark.parametrize("psz", [2, 16, 31, 64])
+def test_extension_patch_sizes_match_oracle(oracle, psz):
+    """Patch sizes the reference cannot run (Eigen alignment) but whose geometry it defines
+    (offsets -(P - P/2) ...). Oracle = our restatement: parity unpinned by the reference."""
+    sc = scene(640, 368, 40, seed=40 + psz, margin=80.0)
+    pr = Pair(oracle, sc, 2, 0, psz, 5, 0.0, 0, 1 if psz == 31 else 0)
+    pr.set_points()
+    pr.set_pose()
+    po, pg = pr.track()
+    _check_patches(pr, exact_T=psz != 31)
+    _check_trace(pr)
+    assert np.abs(po - pg).max() <= POSE_TOL
+
+
+def test_identity_kat_on_gpu(oracle):
+    """Same image twice => delta_p == 0 => p_out == (double)(float)p_in (run_io_reprojection_test.cpp:15)."""
+    sc = scene(640, 368, 100, seed=3)
+    pr = Pair(oracle, sc, 3, 0, 8, 5, 0.1, 0, 0)
+    pr.set_points()
+    pr.otr.setpose(sc["p_a"], pr.opa, pr.opa)
+    pr.odo.SetPose(sc["p_a"], pr.gpa, pr.gpa)
+    po, pg = pr.track()
+    assert np.array_equal(pg, sc["p_a"].astype(np.float32).astype(np.float64)) and np.array_equal(po, pg)
+    tg = pr.odo.trace()
+    assert all(np.all(r["dp"] == 0) for r in tg) and len(tg) == 4  # one iteration per level, then 0/0 stops the loop
+
+
+def test_results_are_deterministic(oracle):
+    sc = scene(640, 368, 300, seed=8)
+    outs = []
+    for _ in range(3):
+        pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, 0)
+        pr.odo.Set3Dpoints(sc["pts3d"].copy())
+        pr.odo.SetPose(sc["p_a"], pr.gpa, pr.gpb)
+        outs.append((pr.odo.TrackPose(), [r["dp"] for r in pr.odo.trace()]))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0])
+        assert all(np.array_equal(x, y) for x, y in zip(o[1], outs[0][1]))
+
+
+def test_lds_window_variant_is_bit_identical(oracle):
+    sc = scene(640, 368, 300, seed=9)
+    res = []
+    for variant in (0, 1):
+        pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, 0, variant=variant)
+        pr.odo.Set3Dpoints(sc["pts3d"].copy())
+        pr.odo.SetPose(sc["p_a"], pr.gpa, pr.gpb)
+        res.append((pr.odo.TrackPose(), pr.odo.trace()))
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a["b"], b["b"]) and np.array_equal(a["dp"], b["dp"])
+    pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, 1, variant=1)  # with patch-mean normalisation, vs the oracle
+    pr.set_points()
+    pr.set_pose()
+    po, pg = pr.track()
+    assert np.abs(po - pg).max() <= POSE_TOL
+
+
+def test_points_out_of_view_and_stale_state_across_frames(oracle):
+    """run_track_nposes chains SetPose/TrackPose without Set3Dpoints (run_track_nposes.cpp:232-258): points that
+    leave the reference view keep their previous patches and sd coefficients in H and b (odometer.cpp:304).
+    GPU and oracle must agree through such a chain."""
+    sc = scene(640, 368, 200, seed=13)
+    pr = Pair(oracle, sc, 3, 0, 8, 5, 0.0, 0, 0)
+    pr.set_points()
+    pr.set_pose()
+    po, pg = pr.track()
+    assert np.abs(po - pg).max() <= POSE_TOL
+    # second frame pair of the chain: start from a pose that pushes ~half of the points out of the reference view
+    p2 = po.copy()
+    p2[0] += 2.4  # translate the camera: points shift by ~ f * 2.4 / depth = 180 px
+    pr.otr.setpose(p2, pr.opb, pr.opa)
+    pr.odo.SetPose(p2, pr.gpb, pr.gpa)
+    vis0 = pr.otr.pt2d(0)[:pr.n]
+    assert 0.15 < np.mean((vis0 < 0) | (vis0 > 640)) < 0.85
+    _check_setup_bit_exact(pr, range(0, 4))
+    po2, pg2 = pr.track()
+    ind = pr.otr.ind(0)[:pr.n]
+    assert 0 < ind.sum() < pr.n
+    _check_patches(pr)          # includes the stale patches of the invisible points
+    coef = pr.odo.read_buffer(7, 16 * pr.M).reshape(-1, 16)
+    assert np.all(np.abs(coef[:pr.n, :12]).sum(1) > 0)  # invisible points still carry (stale) coefficients
+    to, tg = pr.otr.trace(), pr.odo.trace()
+    assert len(to) == len(tg)
+    assert rel(to[0]["H"], tg[0]["H"]) <= SUM_TOL and rel(to[0]["b"], tg[0]["b"]) <= 1e-5
+    assert np.abs(po2 - pg2).max() <= POSE_TOL * max(1.0, np.abs(po2).max())
+
+
+def test_all_points_out_of_view_gives_zero_update(oracle):
+    sc = scene(320, 240, 60, seed=6)
+    pr = Pair(oracle, sc, 2, 0, 8, 4, 0.0, 0, 0)
+    pts = sc["pts3d"].copy()
+    pts[0] += 1000.0
+    pr.set_points(pts)
+    pr.set_pose()
+    po, pg = pr.track()
+    assert np.array_equal(pg, sc["p_a"].astype(np.float32).astype(np.float64)) and np.array_equal(po, pg)
+    assert all(np.all(r["H"] == 0) and np.all(r["dp"] == 0) for r in pr.odo.trace())
+
+
+def test_empty_and_truncated_point_sets(oracle):
+    sc = scene(320, 240, 50, seed=7)
+    pr = Pair(oracle, sc, 1, 0, 8, 3, 0.0, 0, 0, maxpt=24)  # more points than maxpttrack: truncated (odometer.cpp:182)
+    assert pr.M == 24
+    pr.set_points()
+    pr.set_pose()
+    po, pg = pr.track()
+    assert np.abs(po - pg).max() <= POSE_TOL
+    empty = np.zeros((3, 0))
+    pr.otr.set3dpoints(empty.copy())
+    pr.odo.Set3Dpoints(empty.copy(), 0)
+    pr.set_pose()
+    po, pg = pr.track()
+    assert np.array_equal(po, pg) and np.array_equal(pg, sc["p_a"].astype(np.float32).astype(np.float64))
+
+
+def test_nan_points_are_masked_not_fatal(oracle):
+    """The reference would index out of bounds on a NaN projection; the HIP path treats it as out of view."""
+    sc = scene(320, 240, 64, seed=17)
+    pr = Pair(oracle, sc, 1, 0, 8, 3, 0.0, 0, 0)
+    pts = sc["pts3d"].copy()
+    pts[:, 5] = np.nan
+    pts[2, 9] = 0.0  # zero depth after the pose transform is unlikely exactly, but inf/NaN paths are covered by col 5
+    pr.odo.Set3Dpoints(np.ascontiguousarray(pts))
+    pr.odo.SetPose(sc["p_a"], pr.gpa, pr.gpb)
+    out = pr.odo.TrackPose()
+    assert np.all(np.isfinite(out)) and np.abs(out - sc["p_b"]).max() < 5e-3
+
+
+def test_setpose_host_planes_equals_device_pyramids(oracle):
+    """The reference's literal SetPose signature (host level-pointer arrays) against the device-pyramid form."""
+    sc = scene(320, 240, 120, seed=19)
+    pr = Pair(oracle, sc, 2, 0, 8, 5, 0.0, 0, 0)
+    pr.set_points()
+    pr.set_pose()
+    _, pg = pr.track()
+    odo2 = ic.OdometerClass(pr.pose, pr.op)
+    odo2.Set3Dpoints(sc["pts3d"].copy())
+    odo2.SetPose_host(sc["p_a"], pr.opa.img, pr.opa.dx, pr.opa.dy, pr.opb.img)  # the oracle's host planes
+    assert np.array_equal(odo2.TrackPose(), pg)
+
+
+def test_pose_class_projection_api(oracle):
+    sc = scene(320, 240, 30, seed=23)
+    pr = Pair(oracle, sc, 2, 0, 8, 1, 0.0, 0, 0)
+    pr.set_points()
+    pr.set_pose()
+    M, n = pr.M, pr.n
+    p3 = pr.otr.buffer(4, 3 * M)
+    for sc_l in range(3):
+        got = pr.pose.project_pt(p3, n, sc_l)
+        assert np.array_equal(got[:n], pr.otr.pt2d(sc_l)[:n]) and np.array_equal(got[M:M + n], pr.otr.pt2d(sc_l)[M:M + n])
+    rot, got = pr.pose.project_pt_save_rotated(p3, n, 2)
+    assert np.array_equal(rot[:n], pr.otr.buffer(5, 3 * M)[:n])
+    pr.pose.addpose_se3(np.array([1e-2, 0, 0, 0, 1e-3, 0], np.float32))
+    assert not np.array_equal(pr.pose.project_pt(p3, n, 0)[:n], pr.otr.pt2d(0)[:n])
+
+
+def test_batch_equals_single_problems(oracle):
+    """B problems in one launch == B OdometerClass runs (different grid => sums to tolerance, not bitwise)."""
+    scs = [scene(640, 368, 200 + 16 * k, seed=50 + k) for k in range(3)]
+    M = 256
+    op = ic.optparam(2, 0, 8, 6, 0.01, 1, 0, M)
+    cam = ic.CamClass(3, scs[0]["fc"], scs[0]["cc"], scs[0]["wh"], 8)
+    batch = ic.TrackBatch(cam, op, 3)
+    pyrs, singles = [], []
+    for k, sc in enumerate(scs):
+        pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+        pyrs.append((pa, pb))
+        batch.Set3Dpoints(k, sc["pts3d"].copy())
+        batch.SetPose(k, sc["p_a"], pa, pb)
+        pose = ic.PoseClass(cam, op)
+        odo = ic.OdometerClass(pose, op)
+        odo.Set3Dpoints(sc["pts3d"].copy())
+        odo.SetPose(sc["p_a"], pa, pb)
+        singles.append((odo.TrackPose(), odo.Get2DPoints(), len(odo.enable_trace() or []) ))
+    batch.track_async()
+    poses = batch.poses()
+    for k, sc in enumerate(scs):
+        assert np.abs(poses[k] - singles[k][0]).max() <= 2e-6
+        assert np.abs(poses[k] - sc["p_b"]).max() < 2e-3
+        n = sc["pts3d"].shape[1]
+        assert np.array_equal(batch.Get2DPoints(k)[:n], singles[k][1][:n])
+    assert np.all(batch.iterations() >= 6) and np.all(batch.iterations() <= 18)
+
+
+def test_sharded_phases_equal_fused_run(oracle):
+    """Points split over two engines, their H / b partial sums added between the phases (what the RCCL
+    all-reduce does across GPUs, emulated in one process): same poses as the unsharded run."""
+    import torch
+    from invcompcamtrack_amd.dist import RED_STRIDE, run_sharded_levels, shard_slices
+    sc = scene(640, 368, 301, seed=61)
+    op = ic.optparam(2, 0, 8, 6, 0.01, 0, 0, 304)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    full = ic.TrackBatch(cam, op, 1)
+    full.Set3Dpoints(0, sc["pts3d"].copy())
+    full.SetPose(0, sc["p_a"], pa, pb)
+    full.track_async()
+    p_full = full.poses()[0]
+
+    class TwoShards:
+        def __init__(self):
+            self.parts, self.red = [], []
+            for lo, hi in shard_slices(301, 2):
+                b = ic.TrackBatch(cam, op, 1)
+                b.enable_sharding(True)
+                r = torch.zeros(RED_STRIDE, dtype=torch.float32, device="cuda")
+                b.set_reduction_buffer(r.data_ptr())
+                b.Set3Dpoints(0, np.ascontiguousarray(sc["pts3d"][:, lo:hi]))
+                b.SetPose(0, sc["p_a"], pa, pb)
+                self.parts.append(b)
+                self.red.append(r)
+
+        def __getattr__(self, name):
+            def call(*a):
+                for b in self.parts:
+                    getattr(b, name)(*a)
+            return call
+
+        def allreduce(self):
+            torch.cuda.synchronize()
+            s = self.red[0] + self.red[1]
+            for r in self.red:
+                r.copy_(s)
+            torch.cuda.synchronize()
+
+    eng = TwoShards()
+    run_sharded_levels(eng, op, eng.allreduce)
+    p0, p1 = eng.parts[0].poses()[0], eng.parts[1].poses()[0]
+    assert np.array_equal(p0, p1)                 # both "ranks" hold the same pose bits
+    assert np.abs(p0 - p_full).max() <= 2e-6
+    assert list(eng.parts[0].iterations()) == list(full.iterations())
+
+
+@pytest.mark.parametrize("wh", [(1920, 1080), (1280, 720)])
+def test_full_size_properties(oracle, wh):
+    """BASELINE.json sizes: properties instead of the (slow) oracle: identity => exact pose; known motion is
+    recovered; a batch repeats bit for bit; the frame-tiling grid really covers 2 073 600 px at 1080p."""
+    w, h = wh
+    sc = scene(w, h, None, seed=71, grid_step=8, margin=4.0)
+    n = sc["pts3d"].shape[1]
+    assert n == (w // 8) * (h // 8)
+    op = ic.optparam(2, 0, 8, 10, 0.0, 0, 0, n)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    batch = ic.TrackBatch(cam, op, 3)
+    for k in range(3):
+        batch.Set3Dpoints(k, sc["pts3d"].copy())
+    batch.SetPose(0, sc["p_a"], pa, pb)
+    batch.SetPose(1, sc["p_a"], pa, pa)   # identity
+    batch.SetPose(2, sc["p_a"], pa, pb)
+    batch.track_async()
+    poses = batch.poses()
+    assert np.array_equal(poses[1], sc["p_a"].astype(np.float32).astype(np.float64))
+    assert np.array_equal(poses[0], poses[2])
+    assert np.abs(poses[0] - sc["p_b"]).max() < 1e-3
+    assert list(batch.iterations()) == [30, 3, 30]
+    # oracle on the same full-size input, one problem (about a second of CPU)
+    oop = oracle.make_op(2, 0, 8, 10, 0.0, 0, 0, n)
+    tr = oracle.Tracker(oop, sc["fc"], sc["cc"], sc["wh"])
+    tr.set3dpoints(sc["pts3d"].copy())
+    tr.setpose(sc["p_a"], oracle.Pyramid(sc["img_a"], 2, 8), oracle.Pyramid(sc["img_b"], 2, 8))
+    assert np.abs(tr.trackpose() - poses[0]).max() <= POSE_TOL

@@ -1,0 +1,69 @@
+"""Bit-exact parity of the pre-step kernels (pyramid builder, patch fetch) with the oracle."""
+import numpy as np
+import pytest
+
+import invcompcamtrack_amd as ic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,lv_f,pad", [((96, 160), 3, 8), ((1080, 1920), 2, 8), ((135, 45), 2, 4),
+                                            ((64, 64), 5, 4), ((37, 53), 1, 31)])
+def test_pyramid_planes_bit_exact(oracle, shape, lv_f, pad):
+    rng = np.random.default_rng(shape[0])
+    for img in (rng.integers(0, 256, shape).astype(np.float32), rng.uniform(0, 255, shape).astype(np.float32)):
+        o = oracle.Pyramid(img, lv_f, pad)
+        g = ic.Pyramid(img, lv_f, pad)
+        for l in range(lv_f + 1):
+            assert g.level_dims(l) == (o.img[l].shape[1], o.img[l].shape[0])
+            for w, ref in ((0, o.img), (1, o.dx), (2, o.dy)):
+                assert np.array_equal(g.download(l, w), ref[l]), (l, w)
+
+
+def test_pyramid_from_device_pointer_and_host_planes(oracle):
+    import torch
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 255, (120, 200)).astype(np.float32)
+    t = torch.from_numpy(img).cuda()
+    g = ic.Pyramid(lv_f=2, imgpadding=8, device_ptr=t.data_ptr(), wh=(200, 120),
+                   stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    o = oracle.Pyramid(img, 2, 8)
+    for l in range(3):
+        assert np.array_equal(g.download(l, 0), o.img[l]) and np.array_equal(g.download(l, 2), o.dy[l])
+    h = ic.Pyramid(lv_f=2, imgpadding=8, wh=(200, 120), host_planes=(o.img, o.dx, o.dy))
+    for l in range(3):
+        assert np.array_equal(h.download(l, 1), o.dx[l])
+
+
+@pytest.mark.parametrize("psz,dpn", [(8, 0), (4, 0), (8, 1), (5, 0), (31, 0), (16, 1)])
+def test_get_patch_bit_exact_incl_borders(oracle, psz, dpn):
+    rng = np.random.default_rng(psz)
+    h, w = 300, 400
+    img = rng.uniform(0, 255, (h, w)).astype(np.float32)
+    o = oracle.Pyramid(img, 1, psz)
+    g = ic.Pyramid(img, 1, psz)
+    op = ic.optparam(1, 0, psz, 1, 0, 0, dpn, 8)
+    oop = oracle.make_op(1, 0, psz, 1, 0, 0, dpn, 8)
+    for level, (ww, hh) in ((0, (w, h)), (1, (w // 2, h // 2))):
+        mids = np.concatenate([
+            rng.uniform([0, 0], [ww, hh], (200, 2)),
+            # corners and edges are legal (inclusive bounds, odometer.cpp:273-276); integers; x >= 256 where
+            # x + 1e-5f == x in float and the taps shift by one pixel (reference quirk, utilities.cpp:66-67)
+            np.array([[0, 0], [ww, hh], [0, hh], [ww, 0], [17, 23], [256, 100], [300, 128.5], [299.99997, 7]],
+                     np.float64)]).astype(np.float32)
+        mids = mids[(mids[:, 0] <= ww) & (mids[:, 1] <= hh)]
+        T = ic.util_getPatch(g, level, mids, op)
+        T2, Gx, Gy = ic.util_getPatch_grad(g, level, mids, op)
+        for k, m in enumerate(mids):
+            ref = oracle.getpatch(o.img[level], m, oop)
+            r3 = oracle.getpatch_grad(o.img[level], o.dx[level], o.dy[level], m, oop)
+            if dpn:
+                assert np.abs(T[k] - ref).max() <= 1e-4 and np.abs(T2[k] - r3[0]).max() <= 1e-4
+            else:
+                assert np.array_equal(T[k], ref) and np.array_equal(T2[k], r3[0]), (level, m)
+            assert np.array_equal(Gx[k], r3[1]) and np.array_equal(Gy[k], r3[2])
+    from invcompcamtrack_amd._lib import IctrError
+    with pytest.raises(IctrError):
+        ic.util_getPatch(g, 0, np.array([[w + 1.0, 5.0]], np.float32), op)  # outside the image: refused, not read
+    assert ic.util_getPatch(g, 0, np.zeros((0, 2), np.float32), op).shape == (0, psz * psz)
