@@ -22,9 +22,9 @@ void launch_getpatch(const float *, const float *, const float *, const float *,
                      float *, hipStream_t);
 void launch_project_generic(const float *, float *, float *, int, int, const float *, LevelCam, hipStream_t);
 void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
-void launch_ref_level(const EngineDev &, const LevelCam &, int, int, hipStream_t);
+void launch_ref_level(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
 void launch_level_finish(const EngineDev &, hipStream_t);
-void launch_iter(const EngineDev &, const LevelCam &, int, int, int, hipStream_t);
+void launch_iter(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, hipStream_t);
 }  // namespace ictr
 
@@ -500,6 +500,7 @@ struct ictr_batch {
   int variant = 0;
   int sharded = 0;
   int gridx = 1;
+  int cpw = 64, gridx8 = 1;  // P=8 fast path: points per wave chunk, workgroups per problem
   bool trace_on = false;
   bool projected = false;
   // device
@@ -761,6 +762,18 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
       ps.cur = ph.cur->img[l];
     }
   }
+  {
+    // P=8 fast path geometry: a wave owns `cpw` consecutive points. Small problems get small chunks (more
+    // waves, latency hidden by occupancy); large batches get 64-point chunks (coalesced stage 1, deep ILP).
+    const int64_t total = (int64_t)std::max(maxpts, 1) * b->B;
+    int cpw = 4;
+    while (cpw < 64 && total / cpw > 16384) cpw *= 2;
+    b->cpw = cpw;
+    const int64_t chunks = ((int64_t)std::max(maxpts, 1) + cpw - 1) / cpw;
+    const int64_t want = (chunks + kWaves - 1) / kWaves;
+    const int64_t capx = std::max<int64_t>(1, (int64_t)b->gridx);  // partial buffers are sized for gridx blocks
+    b->gridx8 = (int)std::min<int64_t>(std::max<int64_t>(want, 1), capx);
+  }
   HIPCHK(hipMemcpyAsync(b->d_st, b->h_st.data(), sizeof(ProbState) * b->B, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_planes, b->h_planes.data(), sizeof(PlaneSet) * b->h_planes.size(), hipMemcpyHostToDevice,
                         b->stream));
@@ -790,7 +803,7 @@ static int level_ok(ictr_batch *b, int level) {
 }
 extern "C" int ictr_batch_level_accumulate(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
-  launch_ref_level(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->stream);
+  launch_ref_level(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -802,7 +815,7 @@ extern "C" int ictr_batch_level_finish(ictr_batch *b, int level) {
 }
 extern "C" int ictr_batch_iter_accumulate(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
-  launch_iter(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->stream);
+  launch_iter(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -819,9 +832,10 @@ static int enqueue_levels(ictr_batch *b) {
   for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
     const LevelCam lc = level_cam(b->cam, sl);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], b->stream));
-    launch_ref_level(e, lc, sl, b->gridx, b->stream);
+    launch_ref_level(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], b->stream));
-    for (int it = 0; it < b->op->maxiter; ++it) launch_iter(e, lc, sl, b->gridx, b->variant, b->stream);
+    for (int it = 0; it < b->op->maxiter; ++it)
+      launch_iter(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
     if (b->timing) {
       HIPCHK(hipEventRecord(b->ev[3 * sl + 2], b->stream));
       b->ev_used[sl] = 1;

@@ -524,6 +524,322 @@ __global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int l
   }
 }
 
+// ================================================================ P = 8 fast path (wave64 == one 8x8 patch)
+// Two stages per chunk of up to 64 consecutive points owned by one wave:
+//   stage 1  one POINT per lane: coalesced reads of the point arrays, projection / visibility / bilinear weights /
+//            tap base index computed once per point (not 64x redundantly per patch);
+//   stage 2  one PATCH per step, the lanes are its 64 pixels: everything that is constant over the patch comes
+//            out of stage 1's registers with v_readlane into SGPRs (weights, base index, visibility) or through
+//            scalar loads (the 12 sd coefficients), so every vector load address is "SGPR base + lane offset"
+//            and no vector load depends on another one: the unrolled loop keeps several patches in flight.
+typedef const float __attribute__((address_space(4))) *kconst_f32;  // forces s_load for wave-uniform reads
+typedef const float __attribute__((address_space(1))) *gconst_f32;  // plane pointers come out of a table in memory:
+                                                                    // tell the compiler they are global, not flat
+
+__device__ __forceinline__ float tap4g(gconst_f32 img, int idx, int sw, const Taps &t) {
+  const float a = img[idx], b = img[idx - 1], c = img[idx - sw], d = img[idx - sw - 1];
+  return t.w0 * a + t.w1 * b + t.w2 * c + t.w3 * d;
+}
+__device__ __forceinline__ float rlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+constexpr int kU = 4;  // patches in flight per wave in stage 2
+
+template <bool LDSWIN, bool PN>
+__global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
+  __shared__ float sW[kWaves][kPartBStride];
+  __shared__ double sRed[kBlock / 8][8];
+  __shared__ float sWin[LDSWIN ? kWaves * kU : 1][LDSWIN ? 96 : 1];
+  __shared__ unsigned sFlag;
+  const int b = blockIdx.y;
+  ProbState &st = e.st[b];
+  if (!st.active) return;
+  const int npts = st.npts;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
+  const float *__restrict__ T = e.T + (size_t)b * M * 64;
+  const float *__restrict__ Gx = e.Gx + (size_t)b * M * 64;
+  const float *__restrict__ Gy = e.Gy + (size_t)b * M * 64;
+  const float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  gconst_f32 cur = (gconst_f32)pl.cur;
+  const int sw = lc.sw;
+
+  float G[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = st.G[k];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int loff = (lane >> 3) * sw + (lane & 7);
+
+  float acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+
+  const int nchunks = (npts + cpw - 1) / cpw;
+  for (int ch = blockIdx.x * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+    const int i0 = ch * cpw;
+    const int cnt = min(cpw, npts - i0);
+    // ---- stage 1: lane j <-> point i0 + j  (step 7, pose.cpp:384-391; ind_new, odometer.cpp:369-377)
+    const bool pv = lane < cnt;
+    const int ip = i0 + (pv ? lane : 0);
+    const float X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
+    const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
+    const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
+    const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
+    const float mx = (tx / tz) * lc.fx + lc.cx;
+    const float my = (ty / tz) * lc.fy + lc.cy;
+    const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
+    const int base_v = tp.row0 * sw + tp.col0;
+    const int vis_v = vis ? 1 : 0;
+
+    // ---- stage 2: kU patches per step; load phase (all loads independent), then compute phase
+    for (int j0 = 0; j0 < cnt; j0 += kU) {
+      float w0[kU], w1[kU], w2[kU], w3[kU], t[kU], gx[kU], gy[kU], ta[kU], tb[kU], tc[kU], td[kU];
+      int pvis[kU], pi[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int jj = min(j0 + u, cnt - 1);  // tail: repeat the last patch with pvis = 0
+        w0[u] = rlane(tp.w0, jj);
+        w1[u] = rlane(tp.w1, jj);
+        w2[u] = rlane(tp.w2, jj);
+        w3[u] = rlane(tp.w3, jj);
+        const int base = rlane(base_v, jj);
+        pvis[u] = (j0 + u < cnt) ? rlane(vis_v, jj) : 0;
+        pi[u] = i0 + jj;
+        const size_t o = (size_t)pi[u] * 64 + lane;
+        t[u] = T[o];
+        gx[u] = Gx[o];
+        gy[u] = Gy[o];
+        if constexpr (LDSWIN) {
+          // 9x9 window, origin (col0-1,row0-1): 81 texels by 64 lanes in two coalesced passes, into wave-private LDS
+          gconst_f32 wp = cur + (base - sw - 1);
+          const int t1 = lane + 64;
+          ta[u] = wp[(lane / 9) * sw + (lane % 9)];
+          tb[u] = (t1 < 81) ? wp[(t1 / 9) * sw + (t1 % 9)] : 0.0f;
+        } else {
+          gconst_f32 cp = cur + base + loff;
+          ta[u] = cp[0];
+          tb[u] = cp[-1];
+          tc[u] = cp[-sw];
+          td[u] = cp[-sw - 1];
+        }
+      }
+      if constexpr (LDSWIN) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          float *win = sWin[wave * kU + u];
+          win[lane] = ta[u];
+          if (lane < 32) win[lane + 64] = tb[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int py = lane >> 3, px = lane & 7;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const float *win = sWin[wave * kU + u];
+          ta[u] = win[(py + 1) * 9 + px + 1];
+          tb[u] = win[(py + 1) * 9 + px];
+          tc[u] = win[py * 9 + px + 1];
+          td[u] = win[py * 9 + px];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        float inew = w0[u] * ta[u] + w1[u] * tb[u] + w2[u] * tc[u] + w3[u] * td[u];  // utilities.cpp:107
+        if constexpr (PN) inew -= wave_sum(inew) / 64.0f;                              // utilities.cpp:111-112
+        const float r = pvis[u] ? (t[u] - inew) : 0.0f;  // pdiff (odometer.cpp:381); invisible points add 0
+        kconst_f32 cf = (kconst_f32)(coefb + (size_t)pi[u] * kCoefStride);
+        float sd[6];
+        sd[0] = gx[u] * cf[0];
+        sd[1] = gy[u] * cf[7];
+#pragma unroll
+        for (int k = 2; k < 6; ++k) sd[k] = gx[u] * cf[k] + gy[u] * cf[6 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += sd[k] * r;  // sd*_proj summed (odometer.cpp:386-404)
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) sW[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+    e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
+  }
+  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
+  {
+    const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    double s = 0.0;
+    const float *pb = e.partb + (size_t)b * gridDim.x * kPartBStride + j;
+    if (j < 6)
+      for (unsigned k = sl; k < gridDim.x; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
+    sRed[sl][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBlock / 8; ++sl) s += sRed[sl][threadIdx.x];
+    if (e.sharded)
+      e.red[(size_t)b * kRedStride + kHUnique + threadIdx.x] = (float)s;
+    else
+      st.b[threadIdx.x] = (float)s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.arrive = 0u;
+    if (!e.sharded) solve_and_update(st, e, level, b);
+  }
+}
+
+// steps 4-6 in the same two-stage form
+template <bool PN>
+__global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
+  __shared__ float sW[kWaves][kPartHStride];
+  __shared__ double sRed[kBlock / 32][32];
+  __shared__ unsigned sFlag;
+  const int b = blockIdx.y;
+  ProbState &st = e.st[b];
+  const int npts = st.npts;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *__restrict__ pt2d = e.pt2d + ((size_t)b * e.nlev + level) * 2 * M;
+  const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
+  float *T = e.T + (size_t)b * M * 64;
+  float *Gx = e.Gx + (size_t)b * M * 64;
+  float *Gy = e.Gy + (size_t)b * M * 64;
+  float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  const int sw = lc.sw;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int loff = (lane >> 3) * sw + (lane & 7);
+
+  float acc[kHUnique];
+#pragma unroll
+  for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
+
+  const int nchunks = (npts + cpw - 1) / cpw;
+  for (int ch = blockIdx.x * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+    const int i0 = ch * cpw;
+    const int cnt = min(cpw, npts - i0);
+    // ---- stage 1: one point per lane: visibility (odometer.cpp:273-282), sd coefficients (:313-326)
+    const bool pv = lane < cnt;
+    const int ip = i0 + (pv ? lane : 0);
+    const float mx = pt2d[ip], my = pt2d[ip + M];
+    const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+    float cx[6], cy[6];
+    float4 *c4 = reinterpret_cast<float4 *>(coefb + (size_t)ip * kCoefStride);
+    if (vis) {
+      sd_coefs(p3r[ip], p3r[ip + M], p3r[ip + 2 * M], lc.fx, lc.fy, cx, cy);
+      c4[0] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+      c4[1] = make_float4(cx[4], cx[5], cy[0], cy[1]);
+      c4[2] = make_float4(cy[2], cy[3], cy[4], cy[5]);
+    } else {  // stale coefficients stay in force (odometer.cpp:304); zeros if the point was never seen
+      const float4 a0 = c4[0], a1 = c4[1], a2 = c4[2];
+      cx[0] = a0.x; cx[1] = a0.y; cx[2] = a0.z; cx[3] = a0.w; cx[4] = a1.x; cx[5] = a1.y;
+      cy[0] = a1.z; cy[1] = a1.w; cy[2] = a2.x; cy[3] = a2.y; cy[4] = a2.z; cy[5] = a2.w;
+    }
+    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
+    const int base_v = tp.row0 * sw + tp.col0;
+    const int vis_v = vis ? 1 : 0;
+
+    // ---- stage 2: patch j, lanes = pixels (utilities.cpp:115-189, odometer.cpp:428-455)
+#pragma unroll 2
+    for (int j = 0; j < cnt; ++j) {
+      Taps tj;
+      tj.w0 = rlane(tp.w0, j);
+      tj.w1 = rlane(tp.w1, j);
+      tj.w2 = rlane(tp.w2, j);
+      tj.w3 = rlane(tp.w3, j);
+      const int base = rlane(base_v, j);
+      const int pvis = rlane(vis_v, j);
+      float sx[6], sy[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        sx[k] = rlane(cx[k], j);
+        sy[k] = rlane(cy[k], j);
+      }
+      const size_t o = (size_t)(i0 + j) * 64 + lane;
+      float gx, gy;
+      if (pvis) {  // wave-uniform branch
+        const int idx = base + loff;
+        float t = tap4g((gconst_f32)pl.ref, idx, sw, tj);
+        if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188
+        gx = tap4g((gconst_f32)pl.dx, idx, sw, tj);
+        gy = tap4g((gconst_f32)pl.dy, idx, sw, tj);
+        T[o] = t;
+        Gx[o] = gx;
+        Gy[o] = gy;
+      } else {
+        gx = Gx[o];
+        gy = Gy[o];
+      }
+      float sd[6];
+      sd[0] = gx * sx[0];
+      sd[1] = gy * sy[1];
+#pragma unroll
+      for (int k = 2; k < 6; ++k) sd[k] = gx * sx[k] + gy * sy[k];
+      int jk = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) acc[jk++] += sd[a] * sd[c];
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < kHUnique; ++j) {
+    const float v = wave_sum(acc[j]);
+    if (lane == 0) sW[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kHUnique) {
+    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+    e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
+  }
+  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
+  {
+    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double s = 0.0;
+    const float *ph = e.partH + (size_t)b * gridDim.x * kPartHStride + j;
+    if (j < kHUnique)
+      for (unsigned k = sl; k < gridDim.x; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
+    sRed[sl][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kHUnique) {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBlock / 32; ++sl) s += sRed[sl][threadIdx.x];
+    sW[0][threadIdx.x] = (float)s;
+  }
+  __syncthreads();
+  if (e.sharded) {
+    if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sW[0][threadIdx.x];
+  } else if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    st.H[threadIdx.x] = sW[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+  }
+  if (threadIdx.x == 0) {
+    st.arrive = 0u;
+    if (!e.sharded) level_reset(st, e);
+  }
+}
+
 // sharded mode: steps 9b-10 on the all-reduced b (red[b][21..26]); every rank does the same arithmetic
 __global__ void k_iter_finish(EngineDev e, int level) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -661,9 +977,16 @@ void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hi
   for (int l = 0; l < e.nlev && l < 16; ++l) ac.lc[l] = cams[l];
   hipLaunchKernelGGL(k_project_ref, dim3((maxpts + kBlock - 1) / kBlock, e.B), dim3(kBlock), 0, s, e, ac);
 }
-void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, hipStream_t s) {
+void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw,
+                      int gridx8, hipStream_t s) {
   const dim3 g(gridx, e.B), blk(kBlock);
-  if (e.P == 8)
+  if (e.P == 8 && !(variant & 2)) {
+    if (e.dopatchnorm)
+      hipLaunchKernelGGL(k_ref8<true>, dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+    else
+      hipLaunchKernelGGL(k_ref8<false>, dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+  }
+  else if (e.P == 8)
     hipLaunchKernelGGL(k_ref_level<8>, g, blk, 0, s, e, lc, level);
   else if (e.P == 4)
     hipLaunchKernelGGL(k_ref_level<4>, g, blk, 0, s, e, lc, level);
@@ -673,9 +996,20 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
 void launch_level_finish(const EngineDev &e, hipStream_t s) {
   hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e);
 }
-void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, hipStream_t s) {
+void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
+                 hipStream_t s) {
   const dim3 g(gridx, e.B), blk(kBlock);
-  if (e.P == 8) {
+  if (e.P == 8 && !(variant & 2)) {
+    const dim3 g8(gridx8, e.B);
+    if ((variant & 1) && e.dopatchnorm)
+      hipLaunchKernelGGL((k_iter8<true, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (variant & 1)
+      hipLaunchKernelGGL((k_iter8<true, false>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_iter8<false, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else
+      hipLaunchKernelGGL((k_iter8<false, false>), g8, blk, 0, s, e, lc, level, cpw);
+  } else if (e.P == 8) {
     if (variant & 1)
       hipLaunchKernelGGL((k_iter<8, true>), g, blk, 0, s, e, lc, level);
     else

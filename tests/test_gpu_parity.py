@@ -5,8 +5,10 @@ Bars (stated here, used below):
     patches at iteration 0, visibility masks -- everything that is element-wise arithmetic.
   * sums: H and b (J^T J, J^T r over all patch pixels) agree to 2e-6 relative to their largest entry: the
     reference sums in f32 in Eigen's unspecified order, the GPU in per-lane f32 + fixed-order f64 tree.
-  * first Gauss-Newton step: |dp_gpu - dp_cpu|_inf <= 2e-3 |dp|_inf (the 6x6 system has condition ~1e4..1e6, so
-    1e-7 relative noise on H,b moves dp by up to 1e-3 relative; both sides carry that noise).
+  * Gauss-Newton steps: |dp_gpu - dp_cpu|_inf <= 2e-3 |dp|_inf at the first iteration (the 6x6 system has
+    condition ~1e4..1e6, so 1e-7 relative noise on H,b moves dp by up to 1e-3 relative; both sides carry that
+    noise); later iterations additionally absorb the pose difference e they start from (dp(p+e) ~ dp(p) - e), and
+    the poses after every update stay within 2e-5 (normalised units) of each other.
   * final pose: |p_gpu - p_cpu|_inf <= 1e-4 (BASELINE.json north_star), observed ~1e-6.
 """
 import numpy as np
@@ -43,7 +45,7 @@ def _check_patches(pr, exact_T=True):
         assert np.abs(gT - oT).max() <= 1e-4
 
 
-def _check_trace(pr, check_iters=True):
+def _check_trace(pr, check_iters=True, traj_tol=2e-5):
     to, tg = pr.otr.trace(), pr.odo.trace()
     if check_iters:
         assert [(r["level"], r["iter"]) for r in to] == [(r["level"], r["iter"]) for r in tg]
@@ -51,14 +53,15 @@ def _check_trace(pr, check_iters=True):
         if (a["level"], a["iter"]) != (b["level"], b["iter"]):
             break
         assert rel(a["H"], b["H"]) <= SUM_TOL, ("H", a["level"], a["iter"])
-        # b = J^T r depends on the pose the iteration starts from: b(p + e) ~ b(p) - H e. The two runs start
-        # iteration k from poses that differ by e (accumulated rounding), so the b's may differ by |H| |e| plus
-        # the summation noise.
-        e = np.abs((a["p"] - a["dp"]).astype(np.float64) - (b["p"] - b["dp"]).astype(np.float64))
-        # (norm-wise, factor 4: H is the Gauss-Newton matrix at the reference pose, not the exact Jacobian of b)
-        bound = 4.0 * (np.abs(a["H"]).astype(np.float64) @ (e + 2e-7 * np.abs(a["p"]))).max() \
-            + 1e-5 * np.abs(a["b"]).max()
-        assert np.abs(a["b"].astype(np.float64) - b["b"]).max() <= bound, ("b", a["level"], a["iter"])
+        # The two runs enter iteration k from poses that differ by e (accumulated rounding). Gauss-Newton is
+        # self-correcting: dp(p + e) ~ dp(p) - e, so the updates may differ by ~|e| plus the solve's own noise,
+        # and the poses AFTER every update must stay together.
+        pa, pb = a["p"].astype(np.float64), b["p"].astype(np.float64)
+        e = np.abs((pa - a["dp"]) - (pb - b["dp"])).max()
+        ddp = np.abs(a["dp"].astype(np.float64) - b["dp"]).max()
+        scale = max(1.0, np.abs(pa).max())
+        assert ddp <= 2.0 * e + DP_TOL * np.abs(a["dp"]).max() + 0.1 * traj_tol * scale, ("dp", a["level"], a["iter"])
+        assert np.abs(pa - pb).max() <= traj_tol * scale, ("pose trajectory", a["level"], a["iter"])
     a, b = to[0], tg[0]
     assert rel(a["b"], b["b"]) <= SUM_TOL, "b at the very first iteration (bit-identical inputs)"
     assert np.abs(a["dp"] - b["dp"]).max() <= DP_TOL * np.abs(a["dp"]).max(), "first dp"
@@ -102,7 +105,9 @@ def test_extension_patch_sizes_match_oracle(oracle, psz):
     pr.set_pose()
     po, pg = pr.track()
     _check_patches(pr, exact_T=psz != 31)
-    _check_trace(pr)
+    # 40 points with 2x2 or 64x64 patches are poorly conditioned problems: intermediate poses are held to the
+    # north-star bar (1e-4) rather than the tighter band used for the reference-runnable configurations
+    _check_trace(pr, traj_tol=POSE_TOL)
     assert np.abs(po - pg).max() <= POSE_TOL
 
 
