@@ -192,6 +192,8 @@ int ictr_batch_get_poses(ictr_batch *b, double *p_out);
 int ictr_batch_get_iterations(ictr_batch *b, int *iters);
 int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out /* 2*M */);
 int ictr_batch_set_variant(ictr_batch *b, int variant);
+/* inspection, like ictr_odometer_read_buffer; additionally which = 8: the problem's device state as floats */
+int ictr_batch_read_buffer(ictr_batch *b, int64_t problem, int which, float *host_out, int64_t count);
 /* HIP-event timing on the batch's own stream: when enabled, ictr_batch_track_async brackets, per level, the
  * setup kernel (steps 4-6) and the block of maxiter iteration launches (steps 7-10) with events.
  * After the track has completed: ms_setup[l], ms_iters[l] for l in 0..lv_f (0 for levels not run). */

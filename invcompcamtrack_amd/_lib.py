@@ -109,6 +109,7 @@ SIGNATURES = {
     "ictr_batch_get_iterations": (C.c_int, [VP, IP]),
     "ictr_batch_get2dpoints": (C.c_int, [VP, I64, FP]),
     "ictr_batch_set_variant": (C.c_int, [VP, C.c_int]),
+    "ictr_batch_read_buffer": (C.c_int, [VP, I64, C.c_int, FP, I64]),
     "ictr_batch_set_timing": (C.c_int, [VP, C.c_int]),
     "ictr_batch_get_level_times": (C.c_int, [VP, FP, FP]),
     "ictr_batch_set_reduction_buffer": (C.c_int, [VP, VP]),

@@ -41,7 +41,7 @@ struct ProbState {
   int active;       // loop condition of odometer.cpp:344-346, evaluated on the device
   int total_iters;  // executed GN iterations, all levels
   int npts;         // nopoints of this problem
-  unsigned arrive;  // last-block ticket counter
+  unsigned reserved_;
   int pad_;
 };
 

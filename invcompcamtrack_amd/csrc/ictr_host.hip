@@ -1014,22 +1014,25 @@ extern "C" int ictr_odometer_trace(ictr_odometer *o, ictr_trace_rec *out, int64_
   if (out && ncopy > 0) HIPCHK(hipMemcpy(out, o->b->d_trace, sizeof(ictr_trace_rec) * ncopy, hipMemcpyDeviceToHost));
   return ICTR_OK;
 }
-extern "C" int ictr_odometer_read_buffer(ictr_odometer *o, int which, float *host_out, int64_t count) {
-  if (!o || !host_out || count < 0) return fail(ICTR_ERR_INVALID, "read_buffer: bad arguments");
-  ictr_batch *b = o->b;
-  const size_t M = b->M, n = b->n;
+// which: 0 T, 1 Gx, 2 Gy (novals*M), 4 pt3d, 5 pt3d_ref (3*M), 7 sd coefficients (16*M), 8 ProbState as floats,
+// 100+l: pt2d of level l (2*M)
+extern "C" int ictr_batch_read_buffer(ictr_batch *b, int64_t problem, int which, float *host_out, int64_t count) {
+  if (!b || !host_out || count < 0 || problem < 0 || problem >= b->B)
+    return fail(ICTR_ERR_INVALID, "read_buffer: bad arguments");
+  const size_t M = b->M, n = b->n, pr = (size_t)problem;
   const float *src = nullptr;
   size_t avail = 0;
   switch (which) {
-    case 0: src = b->d_T; avail = M * n; break;
-    case 1: src = b->d_Gx; avail = M * n; break;
-    case 2: src = b->d_Gy; avail = M * n; break;
-    case 4: src = b->d_pt3d; avail = 3 * M; break;
-    case 5: src = b->d_pt3d_ref; avail = 3 * M; break;
-    case 7: src = b->d_coef; avail = M * kCoefStride; break;
+    case 0: src = b->d_T + pr * M * n; avail = M * n; break;
+    case 1: src = b->d_Gx + pr * M * n; avail = M * n; break;
+    case 2: src = b->d_Gy + pr * M * n; avail = M * n; break;
+    case 4: src = b->d_pt3d + pr * 3 * M; avail = 3 * M; break;
+    case 5: src = b->d_pt3d_ref + pr * 3 * M; avail = 3 * M; break;
+    case 7: src = b->d_coef + pr * M * kCoefStride; avail = M * kCoefStride; break;
+    case 8: src = reinterpret_cast<const float *>(b->d_st + pr); avail = sizeof(ProbState) / sizeof(float); break;
     default:
       if (which >= 100 && which < 100 + b->nlev) {
-        src = b->d_pt2d + (size_t)(which - 100) * 2 * M;
+        src = b->d_pt2d + (pr * b->nlev + (size_t)(which - 100)) * 2 * M;
         avail = 2 * M;
       }
   }
@@ -1037,6 +1040,10 @@ extern "C" int ictr_odometer_read_buffer(ictr_odometer *o, int which, float *hos
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(host_out, src, sizeof(float) * count, hipMemcpyDeviceToHost));
   return ICTR_OK;
+}
+extern "C" int ictr_odometer_read_buffer(ictr_odometer *o, int which, float *host_out, int64_t count) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  return ictr_batch_read_buffer(o->b, 0, which, host_out, count);
 }
 extern "C" int ictr_odometer_get_norm(const ictr_odometer *o, double *meanshift3, double *varval) {
   if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");

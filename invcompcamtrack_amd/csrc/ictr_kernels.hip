@@ -13,9 +13,13 @@
 // bilinear taps are 8 x 32-B row segments, and the six J^T r sums live in per-lane registers across all the
 // patches a wave visits -- one shuffle reduction per wave per launch, not per patch. The steepest-descent
 // images of the reference (6 planes + 6 projected planes, re-zeroed every iteration) are never materialised:
-// a patch carries 12 scalar coefficients. The last workgroup of a problem to finish (agent-scope ticket)
-// reduces the per-block partials in a fixed order, solves the 6x6 system and updates the pose, so one
-// launch == one Gauss-Newton iteration and the host never reads anything back inside the loop.
+// a patch carries 12 scalar coefficients. Every workgroup leaves one partial sum per component; a second, tiny
+// launch (one workgroup per problem: k_level_tail / k_iter_tail) adds them in a fixed order in f64, solves the
+// 6x6 system and updates the pose on the device, so the host never reads anything back inside the loop and the
+// sums are reproducible bit for bit. Doing that reduction inside the big kernel ("last workgroup to arrive")
+// was measured and rejected: it needs one agent-scope release (an L2 write-back scan, buffer_wbl2 sc1) per
+// workgroup, ~4000 per launch, which throttled the L2 for every wave: 310 us per iteration against 141 us for
+// the two-launch form (profiles/r01_notes.md).
 //
 // Arithmetic parity: compiled with -ffp-contract=off; every expression below keeps the reference's
 // operand order, so patches, projections and coefficients are bit-identical to the CPU path; only the
@@ -95,27 +99,6 @@ __device__ __forceinline__ void sd_values(float gx, float gy, const float *cx, c
   for (int k = 2; k < 6; ++k) sd[k] = gx * cx[k] + gy * cy[k];
 }
 
-// Ticket: returns true in every thread of the LAST workgroup (of `nblocks`) to arrive. Producer side follows
-// cdna_hip_programming.md Guideline 16: stores -> vmcnt(0) -> barrier -> one lane agent-release -> vmcnt(0)
-// -> relaxed agent atomic; the last arriver does one agent acquire before anybody reads the partials.
-__device__ __forceinline__ bool arrive_is_last(unsigned *counter, unsigned nblocks, unsigned *s_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned last = (t == nblocks - 1u) ? 1u : 0u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *s_flag = last;
-  }
-  __syncthreads();
-  return *s_flag != 0u;
-}
-
 __device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
   // odometer.cpp:341-346
   st.normdp_init = 1e-10f;
@@ -124,10 +107,12 @@ __device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
   st.active = ((0 < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
 }
 
-// steps 9b + 10 + loop condition, one thread. ws: LDS scratch (>= 36+6 floats, 12 ints).
-__device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, int prob) {
+// steps 9b + 10 + loop condition, one thread. ws: LDS workspace of 64 floats whose first 36+6 hold H and b; the
+// elimination runs on LDS: runtime-indexed private arrays would live in scratch memory, and a kernel that owns
+// scratch is throttled by the scratch ring to a fraction of the CU's wave slots.
+__device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, int prob, float *ws) {
   float dp[6];
-  lu_solve<6>(st.H, st.b, dp);
+  lu_solve_ws<6>(ws, ws + 36, dp, ws + 42, reinterpret_cast<int *>(ws + 48));
   float p[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -210,15 +195,14 @@ __global__ __launch_bounds__(kBlock) void k_project_generic(const float *__restr
   pt2d[i + M] = (ty / tz) * lc.fy + lc.cy;
 }
 
-// ---------------------------------------------------------------- steps 4-6: per level setup
-// PT = compile-time patch size (8 or 4), or 0 = run-time e.P (any size; a wave loops over the pixels).
+// ---------------------------------------------------------------- steps 4-6: per level setup (any patch size)
+// PT = compile-time patch size (4), or 0 = run-time e.P (any size; a wave loops over the pixels). Writes one
+// partial of the 21 unique H entries per workgroup; k_level_tail finishes.
 template <int PT>
 __global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, int level) {
   __shared__ float sW[kWaves][kPartHStride];
-  __shared__ double sRed[kBlock / 32][32];
-  __shared__ unsigned sFlag;
   const int b = blockIdx.y;
-  ProbState &st = e.st[b];
+  const ProbState &st = e.st[b];
   const int npts = st.npts;
   const int P = PT ? PT : e.P;
   const int n = P * P;
@@ -320,16 +304,21 @@ __global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, 
     const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
     e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
   }
-  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
+}
 
-  // last workgroup of this problem: fixed-order reduction of the block partials (f64), publish H.
-  // 8 slices x 32 components: thread (slice, j) sums blocks slice, slice+8, ...; then 8 slices in order.
+// One workgroup per problem: fixed-order f64 reduction of the H partials of `nblk` workgroups (8 slices x 32
+// components, then the slices in order), publish H (or the rank-local sum when sharded), reset the loop state.
+__global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk) {
+  __shared__ double sRed[kBlock / 32][32];
+  __shared__ float sH[32];
+  const int b = blockIdx.x;
+  ProbState &st = e.st[b];
   {
     const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
     double s = 0.0;
-    const float *ph = e.partH + (size_t)b * gridDim.x * kPartHStride + j;
+    const float *ph = e.partH + (size_t)b * nblk * kPartHStride + j;
     if (j < kHUnique)
-      for (unsigned k = sl; k < gridDim.x; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
+      for (int k = sl; k < nblk; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
     sRed[sl][j] = s;
   }
   __syncthreads();
@@ -337,19 +326,18 @@ __global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, 
     double s = 0.0;
 #pragma unroll
     for (int sl = 0; sl < kBlock / 32; ++sl) s += sRed[sl][threadIdx.x];
-    sW[0][threadIdx.x] = (float)s;
+    sH[threadIdx.x] = (float)s;
   }
   __syncthreads();
   if (e.sharded) {
-    if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sW[0][threadIdx.x];
-  } else if (threadIdx.x < 36) {
-    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-    const int lo = r < c ? r : c, hi = r < c ? c : r;
-    st.H[threadIdx.x] = sW[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-  }
-  if (threadIdx.x == 0) {
-    st.arrive = 0u;
-    if (!e.sharded) level_reset(st, e);
+    if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sH[threadIdx.x];
+  } else {
+    if (threadIdx.x < 36) {
+      const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      st.H[threadIdx.x] = sH[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    }
+    if (threadIdx.x == 0) level_reset(st, e);
   }
 }
 
@@ -368,17 +356,13 @@ __global__ void k_level_finish(EngineDev e) {
   if (threadIdx.x == 0) level_reset(st, e);
 }
 
-// ---------------------------------------------------------------- steps 7-10: one Gauss-Newton iteration
-// LDSWIN: stage the (P+1)x(P+1) current-frame window of each patch through wave-private LDS (PT==8 only).
-template <int PT, bool LDSWIN>
+// ---------------------------------------------------------------- steps 7-9a: one Gauss-Newton iteration (any patch size)
+template <int PT>
 __global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int level) {
   __shared__ float sW[kWaves][kPartBStride];
-  __shared__ double sRed[kBlock / 8][8];
-  __shared__ float sWin[LDSWIN ? kWaves : 1][LDSWIN ? 96 : 1];
-  __shared__ unsigned sFlag;
   const int b = blockIdx.y;
-  ProbState &st = e.st[b];
-  if (!st.active) return;  // loop condition of odometer.cpp:344-346, decided by the previous launch
+  const ProbState &st = e.st[b];
+  if (!st.active) return;  // loop condition of odometer.cpp:344-346, decided on the device by the previous tail
   const int npts = st.npts;
   const int P = PT ? PT : e.P;
   const int n = P * P;
@@ -430,238 +414,22 @@ __global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int l
     const Taps tp = make_taps(vis ? mx : 0.0f, vis ? my : 0.0f, pszd2);
     const int base = tp.row0 * lc.sw + tp.col0;
 
-    if constexpr (LDSWIN && PT == 8) {
-      // 9x9 window, origin (col0-1,row0-1): 81 texels by 64 lanes in two coalesced passes (9 row segments of 36 B)
-      float *win = sWin[wave];
-      const int org = base - lc.sw - 1;
-      {
-        const int t0 = lane, t1 = lane + 64;
-        const float v0 = vis ? cur[org + (t0 / 9) * lc.sw + (t0 % 9)] : 0.0f;
-        float v1 = 0.0f;
-        if (vis && t1 < 81) v1 = cur[org + (t1 / 9) * lc.sw + (t1 % 9)];
-        win[t0] = v0;
-        if (t1 < 96) win[t1] = v1;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int py = lane >> 3, px = lane & 7;
-      const float a = win[(py + 1) * 9 + px + 1], bb = win[(py + 1) * 9 + px], c = win[py * 9 + px + 1],
-                  d = win[py * 9 + px];
-      float inew = tp.w0 * a + tp.w1 * bb + tp.w2 * c + tp.w3 * d;
-      __builtin_amdgcn_wave_barrier();
-      if (e.dopatchnorm) {
-        const float s = wave_sum(vis ? inew : 0.0f);
-        inew -= s / (float)n;
-      }
+    float mean = 0.0f;
+    if (e.dopatchnorm) {  // utilities.cpp:111-112
+      float s = 0.0f;
+      for (int q = q0; q < n; q += qstride)
+        if (vis) s += tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
+      s = group_sum(s, gwidth);
+      mean = s / (float)n;
+    }
+    for (int q = q0; q < n; q += qstride) {
       if (vis) {
-        const size_t o = (size_t)i * 64 + lane;
-        const float r = T[o] - inew;
+        const size_t o = (size_t)i * n + q;
+        float inew = tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
+        if (e.dopatchnorm) inew -= mean;
+        const float r = T[o] - inew;  // pdiff (odometer.cpp:381)
         float sd[6];
         sd_values(Gx[o], Gy[o], cx, cy, sd);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += sd[k] * r;
-      }
-    } else {
-      float mean = 0.0f;
-      if (e.dopatchnorm) {  // utilities.cpp:111-112
-        float s = 0.0f;
-        for (int q = q0; q < n; q += qstride)
-          if (vis) s += tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
-        s = group_sum(s, gwidth);
-        mean = s / (float)n;
-      }
-      for (int q = q0; q < n; q += qstride) {
-        if (vis) {
-          const size_t o = (size_t)i * n + q;
-          float inew = tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
-          if (e.dopatchnorm) inew -= mean;
-          const float r = T[o] - inew;  // pdiff (odometer.cpp:381)
-          float sd[6];
-          sd_values(Gx[o], Gy[o], cx, cy, sd);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) acc[k] += sd[k] * r;  // sd*_proj summed (odometer.cpp:386-404)
-        }
-      }
-    }
-  }
-
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float v = wave_sum(acc[k]);
-    if (lane == 0) sW[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
-    e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
-  }
-  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
-
-  // fixed-order reduction of the block partials in f64: 32 slices x 8 components, then the slices in order
-  {
-    const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
-    double s = 0.0;
-    const float *pb = e.partb + (size_t)b * gridDim.x * kPartBStride + j;
-    if (j < 6)
-      for (unsigned k = sl; k < gridDim.x; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
-    sRed[sl][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    double s = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < kBlock / 8; ++sl) s += sRed[sl][threadIdx.x];
-    if (e.sharded)
-      e.red[(size_t)b * kRedStride + kHUnique + threadIdx.x] = (float)s;
-    else
-      st.b[threadIdx.x] = (float)s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    st.arrive = 0u;
-    if (!e.sharded) solve_and_update(st, e, level, b);
-  }
-}
-
-// ================================================================ P = 8 fast path (wave64 == one 8x8 patch)
-// Two stages per chunk of up to 64 consecutive points owned by one wave:
-//   stage 1  one POINT per lane: coalesced reads of the point arrays, projection / visibility / bilinear weights /
-//            tap base index computed once per point (not 64x redundantly per patch);
-//   stage 2  one PATCH per step, the lanes are its 64 pixels: everything that is constant over the patch comes
-//            out of stage 1's registers with v_readlane into SGPRs (weights, base index, visibility) or through
-//            scalar loads (the 12 sd coefficients), so every vector load address is "SGPR base + lane offset"
-//            and no vector load depends on another one: the unrolled loop keeps several patches in flight.
-typedef const float __attribute__((address_space(4))) *kconst_f32;  // forces s_load for wave-uniform reads
-typedef const float __attribute__((address_space(1))) *gconst_f32;  // plane pointers come out of a table in memory:
-                                                                    // tell the compiler they are global, not flat
-
-__device__ __forceinline__ float tap4g(gconst_f32 img, int idx, int sw, const Taps &t) {
-  const float a = img[idx], b = img[idx - 1], c = img[idx - sw], d = img[idx - sw - 1];
-  return t.w0 * a + t.w1 * b + t.w2 * c + t.w3 * d;
-}
-__device__ __forceinline__ float rlane(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-
-constexpr int kU = 4;  // patches in flight per wave in stage 2
-
-template <bool LDSWIN, bool PN>
-__global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
-  __shared__ float sW[kWaves][kPartBStride];
-  __shared__ double sRed[kBlock / 8][8];
-  __shared__ float sWin[LDSWIN ? kWaves * kU : 1][LDSWIN ? 96 : 1];
-  __shared__ unsigned sFlag;
-  const int b = blockIdx.y;
-  ProbState &st = e.st[b];
-  if (!st.active) return;
-  const int npts = st.npts;
-  const int M = e.M;
-  const PlaneSet pl = e.planes[b * e.nlev + level];
-  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
-  const float *__restrict__ T = e.T + (size_t)b * M * 64;
-  const float *__restrict__ Gx = e.Gx + (size_t)b * M * 64;
-  const float *__restrict__ Gy = e.Gy + (size_t)b * M * 64;
-  const float *coefb = e.coef + (size_t)b * M * kCoefStride;
-  gconst_f32 cur = (gconst_f32)pl.cur;
-  const int sw = lc.sw;
-
-  float G[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) G[k] = st.G[k];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int loff = (lane >> 3) * sw + (lane & 7);
-
-  float acc[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
-
-  const int nchunks = (npts + cpw - 1) / cpw;
-  for (int ch = blockIdx.x * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
-    const int i0 = ch * cpw;
-    const int cnt = min(cpw, npts - i0);
-    // ---- stage 1: lane j <-> point i0 + j  (step 7, pose.cpp:384-391; ind_new, odometer.cpp:369-377)
-    const bool pv = lane < cnt;
-    const int ip = i0 + (pv ? lane : 0);
-    const float X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
-    const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
-    const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
-    const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
-    const float mx = (tx / tz) * lc.fx + lc.cx;
-    const float my = (ty / tz) * lc.fy + lc.cy;
-    const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
-    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
-    const int base_v = tp.row0 * sw + tp.col0;
-    const int vis_v = vis ? 1 : 0;
-
-    // ---- stage 2: kU patches per step; load phase (all loads independent), then compute phase
-    for (int j0 = 0; j0 < cnt; j0 += kU) {
-      float w0[kU], w1[kU], w2[kU], w3[kU], t[kU], gx[kU], gy[kU], ta[kU], tb[kU], tc[kU], td[kU];
-      int pvis[kU], pi[kU];
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const int jj = min(j0 + u, cnt - 1);  // tail: repeat the last patch with pvis = 0
-        w0[u] = rlane(tp.w0, jj);
-        w1[u] = rlane(tp.w1, jj);
-        w2[u] = rlane(tp.w2, jj);
-        w3[u] = rlane(tp.w3, jj);
-        const int base = rlane(base_v, jj);
-        pvis[u] = (j0 + u < cnt) ? rlane(vis_v, jj) : 0;
-        pi[u] = i0 + jj;
-        const size_t o = (size_t)pi[u] * 64 + lane;
-        t[u] = T[o];
-        gx[u] = Gx[o];
-        gy[u] = Gy[o];
-        if constexpr (LDSWIN) {
-          // 9x9 window, origin (col0-1,row0-1): 81 texels by 64 lanes in two coalesced passes, into wave-private LDS
-          gconst_f32 wp = cur + (base - sw - 1);
-          const int t1 = lane + 64;
-          ta[u] = wp[(lane / 9) * sw + (lane % 9)];
-          tb[u] = (t1 < 81) ? wp[(t1 / 9) * sw + (t1 % 9)] : 0.0f;
-        } else {
-          gconst_f32 cp = cur + base + loff;
-          ta[u] = cp[0];
-          tb[u] = cp[-1];
-          tc[u] = cp[-sw];
-          td[u] = cp[-sw - 1];
-        }
-      }
-      if constexpr (LDSWIN) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          float *win = sWin[wave * kU + u];
-          win[lane] = ta[u];
-          if (lane < 32) win[lane + 64] = tb[u];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int py = lane >> 3, px = lane & 7;
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const float *win = sWin[wave * kU + u];
-          ta[u] = win[(py + 1) * 9 + px + 1];
-          tb[u] = win[(py + 1) * 9 + px];
-          tc[u] = win[py * 9 + px + 1];
-          td[u] = win[py * 9 + px];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        float inew = w0[u] * ta[u] + w1[u] * tb[u] + w2[u] * tc[u] + w3[u] * td[u];  // utilities.cpp:107
-        if constexpr (PN) inew -= wave_sum(inew) / 64.0f;                              // utilities.cpp:111-112
-        const float r = pvis[u] ? (t[u] - inew) : 0.0f;  // pdiff (odometer.cpp:381); invisible points add 0
-        kconst_f32 cf = (kconst_f32)(coefb + (size_t)pi[u] * kCoefStride);
-        float sd[6];
-        sd[0] = gx[u] * cf[0];
-        sd[1] = gy[u] * cf[7];
-#pragma unroll
-        for (int k = 2; k < 6; ++k) sd[k] = gx[u] * cf[k] + gy[u] * cf[6 + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] += sd[k] * r;  // sd*_proj summed (odometer.cpp:386-404)
       }
@@ -678,15 +446,26 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
     e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
   }
-  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
+}
+
+// One workgroup per problem: fixed-order f64 reduction of the b partials (32 slices x 8 components, then the
+// slices in order) and steps 9b-10 (solve, pose update, loop condition) -- or, when the points are sharded over
+// ranks, just the rank-local sum into red[] for the all-reduce.
+__global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, int nblk) {
+  __shared__ double sRed[kBlock / 8][8];
+  __shared__ float sLU[64];
+  const int b = blockIdx.x;
+  ProbState &st = e.st[b];
+  if (!st.active) return;
   {
     const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
     double s = 0.0;
-    const float *pb = e.partb + (size_t)b * gridDim.x * kPartBStride + j;
+    const float *pb = e.partb + (size_t)b * nblk * kPartBStride + j;
     if (j < 6)
-      for (unsigned k = sl; k < gridDim.x; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
+      for (int k = sl; k < nblk; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
     sRed[sl][j] = s;
   }
+  if (threadIdx.x >= 64 && threadIdx.x < 100) sLU[threadIdx.x - 64] = st.H[threadIdx.x - 64];
   __syncthreads();
   if (threadIdx.x < 6) {
     double s = 0.0;
@@ -694,24 +473,212 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     for (int sl = 0; sl < kBlock / 8; ++sl) s += sRed[sl][threadIdx.x];
     if (e.sharded)
       e.red[(size_t)b * kRedStride + kHUnique + threadIdx.x] = (float)s;
-    else
+    else {
       st.b[threadIdx.x] = (float)s;
+      sLU[36 + threadIdx.x] = (float)s;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    st.arrive = 0u;
-    if (!e.sharded) solve_and_update(st, e, level, b);
+  if (threadIdx.x == 0 && !e.sharded) solve_and_update(st, e, level, b, sLU);
+}
+
+// sharded mode: steps 9b-10 on the all-reduced b (red[b][21..26]); every rank does the same arithmetic
+__global__ void k_iter_finish(EngineDev e, int level) {
+  __shared__ float sLU[64][64];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= e.B) return;
+  ProbState &st = e.st[b];
+  if (!st.active) return;
+  float *ws = sLU[threadIdx.x];
+  for (int k = 0; k < 36; ++k) ws[k] = st.H[k];
+  for (int k = 0; k < 6; ++k) {
+    const float v = e.red[(size_t)b * kRedStride + kHUnique + k];
+    st.b[k] = v;
+    ws[36 + k] = v;
+    e.red[(size_t)b * kRedStride + kHUnique + k] = 0.0f;
+  }
+  solve_and_update(st, e, level, b, ws);
+}
+
+// ================================================================ P = 8 fast path (wave64 == one 8x8 patch)
+// Two stages per chunk of up to 64 consecutive points owned by one wave:
+//   stage 1  one POINT per lane: coalesced reads of the point arrays; projection / visibility / bilinear weights /
+//            tap base index computed once per point (not 64x redundantly per patch), in the reference's exact
+//            arithmetic; the per-point constants go into a wave-private LDS record;
+//   stage 2  one PATCH per step, the lanes are its 64 pixels: T/Gx/Gy are 256-B coalesced rows with a scalar
+//            base, the frame window is read with every cache line requested once, the per-patch constants come
+//            back from LDS as broadcast ds_read_b128. The steps are software-pipelined (double-buffered
+//            registers): the loads of step s+1 are in flight while step s is reduced.
+typedef const float __attribute__((address_space(1))) *gconst_f32;  // plane pointers come out of a table in memory:
+                                                                    // tell the compiler they are global, not flat
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef const f32x2_a4 __attribute__((address_space(1))) *gconst_f32x2;
+
+__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+constexpr int kU = 2;     // patches per stage-2 step; two steps are in flight
+constexpr int kRec = 16;  // floats per point record in LDS: [w0 w1 w2 w3][cx0 cx2 cx3 cx4][cx5 cy1 cy2 cy3][cy4 cy5 vis -]
+
+// The four bilinear taps of a lane's pixel (lanes = 8x8 pixels, row-major) with every cache line of the 9x9 window
+// requested once: one 8-byte load per lane gives (b,a) of its own row; lanes 0..7 also load the row above; all
+// other lanes take (d,c) from the lane one row up (ds_bpermute) when the values are consumed.
+struct TapLoads {
+  f32x2_a4 ab, top;
+};
+__device__ __forceinline__ TapLoads taps_issue(gconst_f32 plane_at_base, int loff, int sw, int lane) {
+  TapLoads t;
+  t.ab = *reinterpret_cast<gconst_f32x2>(plane_at_base + (loff - 1));
+  f32x2_a4 q = {0.0f, 0.0f};
+  if (lane < 8) q = *reinterpret_cast<gconst_f32x2>(plane_at_base + (loff - sw - 1));
+  t.top = q;
+  return t;
+}
+// utilities.cpp:107 with the reference's operand order, never contracted: template and current patch must round
+// identically so that identical frames give a residual of exactly zero (identity KAT)
+__device__ __forceinline__ float taps_blend(const TapLoads &t, float w0, float w1, float w2, float w3, int lane) {
+  const float a = t.ab.y, b = t.ab.x;
+  const float cu = __shfl_up(a, 8, 64), du = __shfl_up(b, 8, 64);
+  const float c = lane < 8 ? t.top.y : cu, d = lane < 8 ? t.top.x : du;
+  return w0 * a + w1 * b + w2 * c + w3 * d;
+}
+
+struct PatchLoads {  // raw load results of one stage-2 step (consumers belong to the reduce phase)
+  float t[kU], gx[kU], gy[kU];
+  TapLoads cur[kU];
+  int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
+};
+
+template <bool PN>
+__global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
+  __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
+  __shared__ float sW[kWaves][kPartBStride];
+  const int b = blockIdx.y;
+  const ProbState &st = e.st[b];
+  if (!st.active) return;
+  const int npts = st.npts;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
+  const float *__restrict__ T = e.T + (size_t)b * M * 64;
+  const float *__restrict__ Gx = e.Gx + (size_t)b * M * 64;
+  const float *__restrict__ Gy = e.Gy + (size_t)b * M * 64;
+  const float *__restrict__ coefb = e.coef + (size_t)b * M * kCoefStride;
+  gconst_f32 cur = (gconst_f32)pl.cur;
+  const int sw = lc.sw;
+
+  float G[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = st.G[k];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int loff = (lane >> 3) * sw + (lane & 7);
+  float *rec = sRec[wave];
+  const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
+
+  float acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+
+  const int nchunks = (npts + cpw - 1) / cpw;
+  for (int ch = blockIdx.x * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+    const int i0 = ch * cpw;
+    const int cnt = min(cpw, npts - i0);
+    // ---- stage 1: lane j <-> point i0 + j  (step 7, pose.cpp:384-391; ind_new, odometer.cpp:369-377)
+    const bool pv = lane < cnt;
+    const int ip = i0 + (pv ? lane : 0);
+    const float X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
+    const float4 *c4 = reinterpret_cast<const float4 *>(coefb + (size_t)ip * kCoefStride);
+    const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2];  // cx0..3 | cx4 cx5 cy0 cy1 | cy2..5
+    const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
+    const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
+    const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
+    const float mx = (tx / tz) * lc.fx + lc.cx;
+    const float my = (ty / tz) * lc.fy + lc.cy;
+    const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
+    const int base_v = tp.row0 * sw + tp.col0;
+    {
+      float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
+      r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
+      r4[1] = make_float4(q0.x, q0.z, q0.w, q1.x);
+      r4[2] = make_float4(q1.y, q1.w, q2.x, q2.y);
+      r4[3] = make_float4(q2.z, q2.w, vis ? 1.0f : 0.0f, 0.0f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 2. The kU patches of a step are nsteps apart (neighbouring points share frame cache lines).
+    const int nsteps = (cnt + kU - 1) / kU;
+    auto issue = [&](PatchLoads &L, int sidx) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int jraw = sidx + u * nsteps;
+        const int jj = min(jraw, cnt - 1);
+        L.rec[u] = (jraw < cnt) ? jj : -1;
+        const int base = rlane(base_v, jj);
+        const size_t po = (size_t)(i0 + jj) * 64;  // wave-uniform: scalar base + 32-bit lane offset
+        L.t[u] = (T + po)[lane];
+        L.gx[u] = (Gx + po)[lane];
+        L.gy[u] = (Gy + po)[lane];
+        L.cur[u] = taps_issue(cur + base, loff, sw, lane);
+      }
+    };
+    auto reduce = [&](const PatchLoads &L) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (L.rec[u] < 0) continue;  // wave-uniform
+        const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
+                     k2 = rec4[L.rec[u] * 4 + 3];
+        float inew = taps_blend(L.cur[u], w.x, w.y, w.z, w.w, lane);
+        if constexpr (PN) inew -= wave_sum(inew) / 64.0f;  // utilities.cpp:111-112
+        const float r = (L.t[u] - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 for points out of view
+        const float gx = L.gx[u], gy = L.gy[u];
+        {
+#pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only: FMA allowed from here on
+          acc[0] += (gx * k0.x) * r;              // sd1 = Gx cx0
+          acc[1] += (gy * k1.y) * r;              // sd2 = Gy cy1
+          acc[2] += (gx * k0.y + gy * k1.z) * r;  // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
+          acc[3] += (gx * k0.z + gy * k1.w) * r;
+          acc[4] += (gx * k0.w + gy * k2.x) * r;
+          acc[5] += (gx * k1.x + gy * k2.y) * r;
+        }
+      }
+    };
+    PatchLoads A, B;
+    issue(A, 0);
+    for (int sidx = 0; sidx < nsteps; sidx += 2) {
+      if (sidx + 1 < nsteps) issue(B, sidx + 1);
+      reduce(A);
+      if (sidx + 2 < nsteps) issue(A, sidx + 2);
+      if (sidx + 1 < nsteps) reduce(B);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the records are rewritten by the next chunk
+  }
+
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) sW[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+    e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
   }
 }
 
-// steps 4-6 in the same two-stage form
+// steps 4-6 for 8x8 patches, same two-stage form (reference patches + gradients, sd coefficients, H partials)
 template <bool PN>
 __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ float sW[kWaves][kPartHStride];
-  __shared__ double sRed[kBlock / 32][32];
-  __shared__ unsigned sFlag;
   const int b = blockIdx.y;
-  ProbState &st = e.st[b];
+  const ProbState &st = e.st[b];
   const int npts = st.npts;
   const int M = e.M;
   const PlaneSet pl = e.planes[b * e.nlev + level];
@@ -721,6 +688,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   float *Gx = e.Gx + (size_t)b * M * 64;
   float *Gy = e.Gy + (size_t)b * M * 64;
   float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
   const int sw = lc.sw;
 
   const int lane = threadIdx.x & 63;
@@ -756,14 +724,14 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     const int base_v = tp.row0 * sw + tp.col0;
     const int vis_v = vis ? 1 : 0;
 
-    // ---- stage 2: patch j, lanes = pixels (utilities.cpp:115-189, odometer.cpp:428-455)
+    // ---- stage 2: patch j, lanes = pixels (utilities.cpp:115-189, odometer.cpp:428-455); two interleaved halves
+    // of the chunk so that consecutive patches (usually frame neighbours) are not in flight together
+    const int half = (cnt + 1) / 2;
 #pragma unroll 2
-    for (int j = 0; j < cnt; ++j) {
-      Taps tj;
-      tj.w0 = rlane(tp.w0, j);
-      tj.w1 = rlane(tp.w1, j);
-      tj.w2 = rlane(tp.w2, j);
-      tj.w3 = rlane(tp.w3, j);
+    for (int jr = 0; jr < 2 * half; ++jr) {
+      const int j = (jr >> 1) + (jr & 1) * half;
+      if (j >= cnt) continue;  // wave-uniform
+      const float w0 = rlane(tp.w0, j), w1 = rlane(tp.w1, j), w2 = rlane(tp.w2, j), w3 = rlane(tp.w3, j);
       const int base = rlane(base_v, j);
       const int pvis = rlane(vis_v, j);
       float sx[6], sy[6];
@@ -772,20 +740,22 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         sx[k] = rlane(cx[k], j);
         sy[k] = rlane(cy[k], j);
       }
-      const size_t o = (size_t)(i0 + j) * 64 + lane;
+      const size_t po = (size_t)(i0 + j) * 64;
       float gx, gy;
       if (pvis) {  // wave-uniform branch
-        const int idx = base + loff;
-        float t = tap4g((gconst_f32)pl.ref, idx, sw, tj);
+        const TapLoads l0 = taps_issue(pref + base, loff, sw, lane);
+        const TapLoads l1 = taps_issue(pdx + base, loff, sw, lane);
+        const TapLoads l2 = taps_issue(pdy + base, loff, sw, lane);
+        float t = taps_blend(l0, w0, w1, w2, w3, lane);
         if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188
-        gx = tap4g((gconst_f32)pl.dx, idx, sw, tj);
-        gy = tap4g((gconst_f32)pl.dy, idx, sw, tj);
-        T[o] = t;
-        Gx[o] = gx;
-        Gy[o] = gy;
+        gx = taps_blend(l1, w0, w1, w2, w3, lane);
+        gy = taps_blend(l2, w0, w1, w2, w3, lane);
+        (T + po)[lane] = t;
+        (Gx + po)[lane] = gx;
+        (Gy + po)[lane] = gy;
       } else {
-        gx = Gx[o];
-        gy = Gy[o];
+        gx = (Gx + po)[lane];
+        gy = (Gy + po)[lane];
       }
       float sd[6];
       sd[0] = gx * sx[0];
@@ -810,47 +780,6 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
     e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
   }
-  if (!arrive_is_last(&st.arrive, gridDim.x, &sFlag)) return;
-  {
-    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    double s = 0.0;
-    const float *ph = e.partH + (size_t)b * gridDim.x * kPartHStride + j;
-    if (j < kHUnique)
-      for (unsigned k = sl; k < gridDim.x; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
-    sRed[sl][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kHUnique) {
-    double s = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < kBlock / 32; ++sl) s += sRed[sl][threadIdx.x];
-    sW[0][threadIdx.x] = (float)s;
-  }
-  __syncthreads();
-  if (e.sharded) {
-    if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sW[0][threadIdx.x];
-  } else if (threadIdx.x < 36) {
-    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-    const int lo = r < c ? r : c, hi = r < c ? c : r;
-    st.H[threadIdx.x] = sW[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-  }
-  if (threadIdx.x == 0) {
-    st.arrive = 0u;
-    if (!e.sharded) level_reset(st, e);
-  }
-}
-
-// sharded mode: steps 9b-10 on the all-reduced b (red[b][21..26]); every rank does the same arithmetic
-__global__ void k_iter_finish(EngineDev e, int level) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= e.B) return;
-  ProbState &st = e.st[b];
-  if (!st.active) return;
-  for (int k = 0; k < 6; ++k) {
-    st.b[k] = e.red[(size_t)b * kRedStride + kHUnique + k];
-    e.red[(size_t)b * kRedStride + kHUnique + k] = 0.0f;
-  }
-  solve_and_update(st, e, level, b);
 }
 
 // ---------------------------------------------------------------- util_getPatch(_grad) for callers (NCC scoring etc.)
@@ -977,47 +906,42 @@ void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hi
   for (int l = 0; l < e.nlev && l < 16; ++l) ac.lc[l] = cams[l];
   hipLaunchKernelGGL(k_project_ref, dim3((maxpts + kBlock - 1) / kBlock, e.B), dim3(kBlock), 0, s, e, ac);
 }
-void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw,
-                      int gridx8, hipStream_t s) {
-  const dim3 g(gridx, e.B), blk(kBlock);
+// steps 4-6 of one level for every problem: accumulate kernel + per-problem tail
+void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
+                      hipStream_t s) {
+  const dim3 blk(kBlock);
+  int nblk = gridx;
   if (e.P == 8 && !(variant & 2)) {
+    nblk = gridx8;
     if (e.dopatchnorm)
       hipLaunchKernelGGL(k_ref8<true>, dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
     else
       hipLaunchKernelGGL(k_ref8<false>, dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
-  }
-  else if (e.P == 8)
-    hipLaunchKernelGGL(k_ref_level<8>, g, blk, 0, s, e, lc, level);
-  else if (e.P == 4)
-    hipLaunchKernelGGL(k_ref_level<4>, g, blk, 0, s, e, lc, level);
+  } else if (e.P == 4)
+    hipLaunchKernelGGL(k_ref_level<4>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
-    hipLaunchKernelGGL(k_ref_level<0>, g, blk, 0, s, e, lc, level);
+    hipLaunchKernelGGL(k_ref_level<0>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
+  hipLaunchKernelGGL(k_level_tail, dim3(e.B), blk, 0, s, e, nblk);
 }
 void launch_level_finish(const EngineDev &e, hipStream_t s) {
   hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e);
 }
+// steps 7-10 of one Gauss-Newton iteration for every problem: accumulate kernel + per-problem tail
 void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
                  hipStream_t s) {
-  const dim3 g(gridx, e.B), blk(kBlock);
+  const dim3 blk(kBlock);
+  int nblk = gridx;
   if (e.P == 8 && !(variant & 2)) {
-    const dim3 g8(gridx8, e.B);
-    if ((variant & 1) && e.dopatchnorm)
-      hipLaunchKernelGGL((k_iter8<true, true>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (variant & 1)
-      hipLaunchKernelGGL((k_iter8<true, false>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_iter8<false, true>), g8, blk, 0, s, e, lc, level, cpw);
+    nblk = gridx8;
+    if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_iter8<true>), dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL((k_iter8<false, false>), g8, blk, 0, s, e, lc, level, cpw);
-  } else if (e.P == 8) {
-    if (variant & 1)
-      hipLaunchKernelGGL((k_iter<8, true>), g, blk, 0, s, e, lc, level);
-    else
-      hipLaunchKernelGGL((k_iter<8, false>), g, blk, 0, s, e, lc, level);
+      hipLaunchKernelGGL((k_iter8<false>), dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
-    hipLaunchKernelGGL((k_iter<4, false>), g, blk, 0, s, e, lc, level);
+    hipLaunchKernelGGL((k_iter<4>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
-    hipLaunchKernelGGL((k_iter<0, false>), g, blk, 0, s, e, lc, level);
+    hipLaunchKernelGGL((k_iter<0>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
+  hipLaunchKernelGGL(k_iter_tail, dim3(e.B), blk, 0, s, e, level, nblk);
 }
 void launch_iter_finish(const EngineDev &e, int level, hipStream_t s) {
   hipLaunchKernelGGL(k_iter_finish, dim3((e.B + 63) / 64), dim3(64), 0, s, e, level);

@@ -204,4 +204,83 @@ template <int N> ICTR_HD void lu_solve(const float *Hin, const float *bin, float
   }
 }
 
+// Same algorithm with every runtime-indexed array in caller-provided storage (LDS on the device): A (N*N, destroyed),
+// b (N, read), c (N scratch), piv (2N ints scratch). Bit-identical to lu_solve.
+template <int N> ICTR_HD void lu_solve_ws(float *A, const float *bin, float *x, float *c, int *piv) {
+  int *rowsw = piv, *colsw = piv + N;
+  int nonzero = N;
+  float maxpiv = 0.0f;
+  for (int k = 0; k < N; ++k) {
+    int br = k, bc = k;
+    float best = fabsf(A[k * N + k]);
+    for (int cc = k; cc < N; ++cc)
+      for (int r = k; r < N; ++r) {
+        const float v = fabsf(A[r * N + cc]);
+        if (v > best) {
+          best = v;
+          br = r;
+          bc = cc;
+        }
+      }
+    if (best == 0.0f) {
+      nonzero = k;
+      for (int i = k; i < N; ++i) rowsw[i] = colsw[i] = i;
+      break;
+    }
+    if (best > maxpiv) maxpiv = best;
+    rowsw[k] = br;
+    colsw[k] = bc;
+    if (br != k)
+      for (int cc = 0; cc < N; ++cc) {
+        const float t = A[k * N + cc];
+        A[k * N + cc] = A[br * N + cc];
+        A[br * N + cc] = t;
+      }
+    if (bc != k)
+      for (int r = 0; r < N; ++r) {
+        const float t = A[r * N + k];
+        A[r * N + k] = A[r * N + bc];
+        A[r * N + bc] = t;
+      }
+    if (k < N - 1) {
+      const float pv = A[k * N + k];
+      for (int r = k + 1; r < N; ++r) A[r * N + k] /= pv;
+      for (int cc = k + 1; cc < N; ++cc)
+        for (int r = k + 1; r < N; ++r) A[r * N + cc] -= A[r * N + k] * A[k * N + cc];
+    }
+  }
+  for (int i = 0; i < N; ++i) x[i] = 0.0f;
+  if (nonzero == 0) return;
+  const float thr = maxpiv * (1.1920929e-07f * N);
+  int rank = 0;
+  for (int i = 0; i < nonzero; ++i) rank += (fabsf(A[i * N + i]) > thr) ? 1 : 0;
+  for (int i = 0; i < N; ++i) c[i] = bin[i];
+  for (int k = 0; k < N; ++k) {
+    const int r = rowsw[k];
+    if (r != k) {
+      const float t = c[k];
+      c[k] = c[r];
+      c[r] = t;
+    }
+  }
+  for (int i = 0; i < N; ++i)
+    for (int r = i + 1; r < N; ++r) c[r] -= c[i] * A[r * N + i];
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < rank) {
+      c[i] /= A[i * N + i];
+      for (int r = 0; r < i; ++r) c[r] -= c[i] * A[r * N + i];
+    }
+  }
+  for (int i = 0; i < N; ++i) c[i] = (i < rank) ? c[i] : 0.0f;
+  for (int k = N - 1; k >= 0; --k) {
+    const int q = colsw[k];
+    if (q != k) {
+      const float t = c[k];
+      c[k] = c[q];
+      c[q] = t;
+    }
+  }
+  for (int i = 0; i < N; ++i) x[i] = c[i];
+}
+
 }  // namespace ictr

@@ -373,6 +373,11 @@ class TrackBatch:
         check(_lib.load().ictr_batch_get2dpoints(self._h, problem, fp(out)))
         return out
 
+    def read_buffer(self, problem, which, count):
+        out = np.empty(count, np.float32)
+        check(_lib.load().ictr_batch_read_buffer(self._h, problem, which, fp(out), count))
+        return out
+
     def set_timing(self, on=True):
         check(_lib.load().ictr_batch_set_timing(self._h, int(on)))
 

@@ -10,6 +10,16 @@ Bars (stated here, used below):
     noise); later iterations additionally absorb the pose difference e they start from (dp(p+e) ~ dp(p) - e), and
     the poses after every update stay within 2e-5 (normalised units) of each other.
   * final pose: |p_gpu - p_cpu|_inf <= 1e-4 (BASELINE.json north_star), observed ~1e-6.
+
+Why the per-iteration trajectory checks use frames below 256 px: the reference selects the bilinear taps with
+ceil(x + .00001f) (utilities.cpp:66-67) "to round up full natural numbers". In float32 that addition is absorbed
+for x >= 256, so a projected coordinate that lands EXACTLY on an integer >= 256 samples the whole patch one pixel
+to the left -- a genuine discontinuity of the reference (reproduced bit for bit by the oracle and by the HIP
+kernels, see test_get_patch_bit_exact_incl_borders). With coordinates ~300 it fires with probability ~3e-5 per
+coordinate and iteration; which iteration hits it depends on the last ulp of the pose, so two correct
+implementations can take visibly different steps at one iteration (observed: b jumps by 64*sd*gradient ~ 7e5
+from a 6e-8 pose difference) and then re-converge. Below 256 px the quirk cannot fire and trajectories are
+comparable step by step; above, only first-iteration sums and final poses are.
 """
 import numpy as np
 import pytest
@@ -76,7 +86,9 @@ def _check_trace(pr, check_iters=True, traj_tol=2e-5):
 ])
 def test_tracker_matches_oracle_reference_parameter_sets(oracle, args):
     lv_f, lv_l, psz, maxiter, ratio, donorm, dpn = args
-    sc = scene(640, 368, 257, seed=31 + psz)  # 257: not a multiple of 4 -> maxpttrack padding path
+    # 256 x 224: every coordinate < 256 (no ceil(x+1e-5f) quirk), even sizes down to level 4;
+    # 257 points: not a multiple of 4 -> maxpttrack padding path
+    sc = scene(256, 224, 257, seed=31 + psz, margin=12.0)
     pr = Pair(oracle, sc, lv_f, lv_l, psz, maxiter, ratio, donorm, dpn)
     a, b = pr.set_points()
     assert np.array_equal(a, b)  # Set3Dpoints mutated both inputs identically (donorm)
@@ -92,14 +104,33 @@ def test_tracker_matches_oracle_reference_parameter_sets(oracle, args):
     _check_patches(pr, exact_T=not dpn)
     _check_trace(pr)
     assert np.abs(po - pg).max() <= POSE_TOL
-    assert np.abs(pg - sc["p_b"]).max() < 2e-3  # and it is the right answer
+    assert np.abs(pg - sc["p_b"]).max() < 5e-3  # and it is the right answer
+
+
+@pytest.mark.parametrize("args", [(4, 0, 8, 10, 0.01, 1, 1), (4, 0, 4, 5, 0.01, 0, 0)])
+def test_tracker_matches_oracle_vga_frames(oracle, args):
+    """640 x 368 frames (coordinates beyond 256: the tap-selection quirk may fire at some iteration, see the module
+    docstring): bit-exact setup, first-iteration sums, final pose."""
+    lv_f, lv_l, psz, maxiter, ratio, donorm, dpn = args
+    sc = scene(640, 368, 257, seed=31 + psz)
+    pr = Pair(oracle, sc, lv_f, lv_l, psz, maxiter, ratio, donorm, dpn)
+    pr.set_points()
+    pr.set_pose()
+    _check_setup_bit_exact(pr, range(lv_l, lv_f + 1))
+    po, pg = pr.track()
+    _check_patches(pr, exact_T=not dpn)
+    a, b = pr.otr.trace()[0], pr.odo.trace()[0]
+    assert rel(a["H"], b["H"]) <= SUM_TOL and rel(a["b"], b["b"]) <= SUM_TOL
+    assert np.abs(a["dp"] - b["dp"]).max() <= DP_TOL * np.abs(a["dp"]).max()
+    assert np.abs(po - pg).max() <= POSE_TOL
+    assert np.abs(pg - sc["p_b"]).max() < 2e-3
 
 
 @pytest.mark.parametrize("psz", [2, 16, 31, 64])
 def test_extension_patch_sizes_match_oracle(oracle, psz):
     """Patch sizes the reference cannot run (Eigen alignment) but whose geometry it defines
     (offsets -(P - P/2) ...). Oracle = our restatement: parity unpinned by the reference."""
-    sc = scene(640, 368, 40, seed=40 + psz, margin=80.0)
+    sc = scene(256, 224, 40, seed=40 + psz, margin=40.0)  # < 256 px: see the module docstring
     pr = Pair(oracle, sc, 2, 0, psz, 5, 0.0, 0, 1 if psz == 31 else 0)
     pr.set_points()
     pr.set_pose()
@@ -137,22 +168,23 @@ def test_results_are_deterministic(oracle):
         assert all(np.array_equal(x, y) for x, y in zip(o[1], outs[0][1]))
 
 
-def test_lds_window_variant_is_bit_identical(oracle):
-    sc = scene(640, 368, 300, seed=9)
+def test_fast_path_equals_generic_path(oracle):
+    """P = 8 has a specialised kernel pair (k_ref8 / k_iter8); variant bit 1 forces the any-size kernels instead.
+    Same arithmetic per element, different summation order: identical setup buffers, poses to float noise."""
+    sc = scene(256, 224, 300, seed=9, margin=12.0)
     res = []
-    for variant in (0, 1):
-        pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, 0, variant=variant)
-        pr.odo.Set3Dpoints(sc["pts3d"].copy())
-        pr.odo.SetPose(sc["p_a"], pr.gpa, pr.gpb)
-        res.append((pr.odo.TrackPose(), pr.odo.trace()))
-    assert np.array_equal(res[0][0], res[1][0])
-    for a, b in zip(res[0][1], res[1][1]):
-        assert np.array_equal(a["b"], b["b"]) and np.array_equal(a["dp"], b["dp"])
-    pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, 1, variant=1)  # with patch-mean normalisation, vs the oracle
-    pr.set_points()
-    pr.set_pose()
-    po, pg = pr.track()
-    assert np.abs(po - pg).max() <= POSE_TOL
+    for variant in (0, 2):
+        for dpn in (0, 1):
+            pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, dpn, variant=variant)
+            pr.set_points()
+            pr.set_pose()
+            po, pg = pr.track()
+            assert np.abs(po - pg).max() <= POSE_TOL
+            res.append((pg, pr.odo.read_buffer(0, 64 * 300), pr.odo.read_buffer(1, 64 * 300), pr.odo.read_buffer(7, 16 * 300)))
+    for k in (0, 1):
+        fast, gen = res[k], res[2 + k]
+        assert np.abs(fast[0] - gen[0]).max() <= 2e-6
+        assert np.array_equal(fast[1], gen[1]) and np.array_equal(fast[2], gen[2]) and np.array_equal(fast[3], gen[3])
 
 
 def test_points_out_of_view_and_stale_state_across_frames(oracle):
@@ -257,7 +289,7 @@ def test_pose_class_projection_api(oracle):
 
 def test_batch_equals_single_problems(oracle):
     """B problems in one launch == B OdometerClass runs (different grid => sums to tolerance, not bitwise)."""
-    scs = [scene(640, 368, 200 + 16 * k, seed=50 + k) for k in range(3)]
+    scs = [scene(256, 224, 200 + 16 * k, seed=50 + k, margin=12.0) for k in range(3)]
     M = 256
     op = ic.optparam(2, 0, 8, 6, 0.01, 1, 0, M)
     cam = ic.CamClass(3, scs[0]["fc"], scs[0]["cc"], scs[0]["wh"], 8)
@@ -277,7 +309,7 @@ def test_batch_equals_single_problems(oracle):
     poses = batch.poses()
     for k, sc in enumerate(scs):
         assert np.abs(poses[k] - singles[k][0]).max() <= 2e-6
-        assert np.abs(poses[k] - sc["p_b"]).max() < 2e-3
+        assert np.abs(poses[k] - sc["p_b"]).max() < 5e-3
         n = sc["pts3d"].shape[1]
         assert np.array_equal(batch.Get2DPoints(k)[:n], singles[k][1][:n])
     assert np.all(batch.iterations() >= 6) and np.all(batch.iterations() <= 18)
@@ -288,7 +320,7 @@ def test_sharded_phases_equal_fused_run(oracle):
     all-reduce does across GPUs, emulated in one process): same poses as the unsharded run."""
     import torch
     from invcompcamtrack_amd.dist import RED_STRIDE, run_sharded_levels, shard_slices
-    sc = scene(640, 368, 301, seed=61)
+    sc = scene(256, 224, 301, seed=61, margin=12.0)
     op = ic.optparam(2, 0, 8, 6, 0.01, 0, 0, 304)
     cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
     pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
