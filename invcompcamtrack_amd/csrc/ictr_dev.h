@@ -33,6 +33,9 @@ struct ProbState {
   float p[6];    // cpos_p  (pose.h:54)
   float G[12];   // cpos_G  (pose.h:53)
   float H[36];   // Hes     (odometer.h:62)
+  float LU[36];  // full-pivot LU factors of H, computed once per level (H is constant across its iterations)
+  int piv[12];   // 6 row + 6 column transpositions
+  int luinfo[2]; // non-zero pivots, rank
   float b[6];    // sumsd
   float dp[6];   // delta_p
   float normdp;

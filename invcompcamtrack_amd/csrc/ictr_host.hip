@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -146,7 +147,14 @@ extern "C" void ictr_se3_coeff_to_group_f(float *G, const float *p) { se3_exp<fl
 extern "C" void ictr_se3_coeff_to_group_d(double *G, const double *p) { se3_exp<double>(G, p); }
 extern "C" void ictr_se3_group_to_coeff_f(float *p, const float *G) { se3_log<float>(p, G); }
 extern "C" void ictr_se3_group_to_coeff_d(double *p, const double *G) { se3_log<double>(p, G); }
-extern "C" void ictr_solve6(const float *H, const float *b, float *x) { lu_solve<6>(H, b, x); }
+extern "C" void ictr_solve6(const float *H, const float *b, float *x) {
+  // the device path (factor once per level + substitute per iteration), run back to back on the host
+  float A[36], c[6];
+  int piv[12], info[2];
+  memcpy(A, H, sizeof(A));
+  lu_factor_ws<6>(A, piv, info);
+  lu_apply_ws<6>(A, piv, info, b, x, c);
+}
 
 // pose.cpp:25-76
 static void host_setpose(bool donorm, const double *p_in, const double *ms, double varval, float *p_f, float *G_f) {
@@ -767,7 +775,11 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
     // waves, latency hidden by occupancy); large batches get 64-point chunks (coalesced stage 1, deep ILP).
     const int64_t total = (int64_t)std::max(maxpts, 1) * b->B;
     int cpw = 4;
-    while (cpw < 64 && total / cpw > 16384) cpw *= 2;
+    while (cpw < 64 && total / cpw > 32768) cpw *= 2;
+    if (const char *env = getenv("ICTR_CPW")) {  // experiments only
+      const int v = atoi(env);
+      if (v >= 1 && v <= 64) cpw = v;
+    }
     b->cpw = cpw;
     const int64_t chunks = ((int64_t)std::max(maxpts, 1) + cpw - 1) / cpw;
     const int64_t want = (chunks + kWaves - 1) / kWaves;

@@ -99,6 +99,15 @@ __device__ __forceinline__ void sd_values(float gx, float gy, const float *cx, c
   for (int k = 2; k < 6; ++k) sd[k] = gx * cx[k] + gy * cy[k];
 }
 
+// once per level and problem, one thread: factor the new H (ws: 36 floats of LDS holding H, destroyed)
+__device__ void level_factor(ProbState &st, float *ws, int *iws) {
+  lu_factor_ws<6>(ws, iws, iws + 12);
+  for (int k = 0; k < 36; ++k) st.LU[k] = ws[k];
+  for (int k = 0; k < 12; ++k) st.piv[k] = iws[k];
+  st.luinfo[0] = iws[12];
+  st.luinfo[1] = iws[13];
+}
+
 __device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
   // odometer.cpp:341-346
   st.normdp_init = 1e-10f;
@@ -107,12 +116,13 @@ __device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
   st.active = ((0 < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
 }
 
-// steps 9b + 10 + loop condition, one thread. ws: LDS workspace of 64 floats whose first 36+6 hold H and b; the
-// elimination runs on LDS: runtime-indexed private arrays would live in scratch memory, and a kernel that owns
-// scratch is throttled by the scratch ring to a fraction of the CU's wave slots.
+// steps 9b + 10 + loop condition, one thread. ws: LDS workspace of 64 floats: [0..35] LU factors, [36..41] b,
+// [42..47] scratch, [48..59] transpositions, [60..61] info. Everything runtime-indexed lives in LDS: private arrays
+// would go to scratch memory.
 __device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, int prob, float *ws) {
   float dp[6];
-  lu_solve_ws<6>(ws, ws + 36, dp, ws + 42, reinterpret_cast<int *>(ws + 48));
+  const int *iws = reinterpret_cast<const int *>(ws + 48);
+  lu_apply_ws<6>(ws, iws, iws + 12, ws + 36, dp, ws + 42);
   float p[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -311,6 +321,8 @@ __global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, 
 __global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk) {
   __shared__ double sRed[kBlock / 32][32];
   __shared__ float sH[32];
+  __shared__ float sA[36];
+  __shared__ int sI[16];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
   {
@@ -335,25 +347,38 @@ __global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk) {
     if (threadIdx.x < 36) {
       const int r = threadIdx.x / 6, c = threadIdx.x % 6;
       const int lo = r < c ? r : c, hi = r < c ? c : r;
-      st.H[threadIdx.x] = sH[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+      const float v = sH[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+      st.H[threadIdx.x] = v;
+      sA[threadIdx.x] = v;
     }
-    if (threadIdx.x == 0) level_reset(st, e);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      level_factor(st, sA, sI);
+      level_reset(st, e);
+    }
   }
 }
 
 // sharded mode: adopt the all-reduced H (red[b][0..20]) and reset the iteration state
 __global__ void k_level_finish(EngineDev e) {
+  __shared__ float sA[36];
+  __shared__ int sI[16];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
   if (threadIdx.x < 36) {
     const int r = threadIdx.x / 6, c = threadIdx.x % 6;
     const int lo = r < c ? r : c, hi = r < c ? c : r;
-    st.H[threadIdx.x] = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    const float v = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    st.H[threadIdx.x] = v;
+    sA[threadIdx.x] = v;
   }
   __syncthreads();
   // leave the slot zeroed: the caller may all-reduce the whole buffer again before it is rewritten
   if (threadIdx.x < kRedStride) e.red[(size_t)b * kRedStride + threadIdx.x] = 0.0f;
-  if (threadIdx.x == 0) level_reset(st, e);
+  if (threadIdx.x == 0) {
+    level_factor(st, sA, sI);
+    level_reset(st, e);
+  }
 }
 
 // ---------------------------------------------------------------- steps 7-9a: one Gauss-Newton iteration (any patch size)
@@ -465,7 +490,9 @@ __global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, in
       for (int k = sl; k < nblk; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
     sRed[sl][j] = s;
   }
-  if (threadIdx.x >= 64 && threadIdx.x < 100) sLU[threadIdx.x - 64] = st.H[threadIdx.x - 64];
+  if (threadIdx.x >= 64 && threadIdx.x < 100) sLU[threadIdx.x - 64] = st.LU[threadIdx.x - 64];
+  if (threadIdx.x >= 128 && threadIdx.x < 140) reinterpret_cast<int *>(sLU)[48 + threadIdx.x - 128] = st.piv[threadIdx.x - 128];
+  if (threadIdx.x >= 140 && threadIdx.x < 142) reinterpret_cast<int *>(sLU)[60 + threadIdx.x - 140] = st.luinfo[threadIdx.x - 140];
   __syncthreads();
   if (threadIdx.x < 6) {
     double s = 0.0;
@@ -490,7 +517,10 @@ __global__ void k_iter_finish(EngineDev e, int level) {
   ProbState &st = e.st[b];
   if (!st.active) return;
   float *ws = sLU[threadIdx.x];
-  for (int k = 0; k < 36; ++k) ws[k] = st.H[k];
+  for (int k = 0; k < 36; ++k) ws[k] = st.LU[k];
+  for (int k = 0; k < 12; ++k) reinterpret_cast<int *>(ws)[48 + k] = st.piv[k];
+  reinterpret_cast<int *>(ws)[60] = st.luinfo[0];
+  reinterpret_cast<int *>(ws)[61] = st.luinfo[1];
   for (int k = 0; k < 6; ++k) {
     const float v = e.red[(size_t)b * kRedStride + kHUnique + k];
     st.b[k] = v;
@@ -519,7 +549,6 @@ __device__ __forceinline__ float rlane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-constexpr int kU = 2;     // patches per stage-2 step; two steps are in flight
 constexpr int kRec = 16;  // floats per point record in LDS: [w0 w1 w2 w3][cx0 cx2 cx3 cx4][cx5 cy1 cy2 cy3][cy4 cy5 vis -]
 
 // The four bilinear taps of a lane's pixel (lanes = 8x8 pixels, row-major) with every cache line of the 9x9 window
@@ -545,13 +574,14 @@ __device__ __forceinline__ float taps_blend(const TapLoads &t, float w0, float w
   return w0 * a + w1 * b + w2 * c + w3 * d;
 }
 
-struct PatchLoads {  // raw load results of one stage-2 step (consumers belong to the reduce phase)
+template <int kU>
+struct PatchLoads {  // raw load results of one stage-2 step of kU patches (consumers belong to the reduce phase)
   float t[kU], gx[kU], gy[kU];
   TapLoads cur[kU];
   int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
 };
 
-template <bool PN>
+template <bool PN, int kU>
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartBStride];
@@ -614,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
 
     // ---- stage 2. The kU patches of a step are nsteps apart (neighbouring points share frame cache lines).
     const int nsteps = (cnt + kU - 1) / kU;
-    auto issue = [&](PatchLoads &L, int sidx) {
+    auto issue = [&](PatchLoads<kU> &L, int sidx) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int jraw = sidx + u * nsteps;
@@ -628,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         L.cur[u] = taps_issue(cur + base, loff, sw, lane);
       }
     };
-    auto reduce = [&](const PatchLoads &L) {
+    auto reduce = [&](const PatchLoads<kU> &L) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (L.rec[u] < 0) continue;  // wave-uniform
@@ -649,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         }
       }
     };
-    PatchLoads A, B;
+    PatchLoads<kU> A, B;
     issue(A, 0);
     for (int sidx = 0; sidx < nsteps; sidx += 2) {
       if (sidx + 1 < nsteps) issue(B, sidx + 1);
@@ -673,9 +703,20 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   }
 }
 
-// steps 4-6 for 8x8 patches, same two-stage form (reference patches + gradients, sd coefficients, H partials)
-template <bool PN>
+// steps 4-6 for 8x8 patches, same two-stage, software-pipelined form (reference patches + gradients, sd
+// coefficients, H partials). The patches T/Gx/Gy it stores are bit-exact (un-contracted blends); only the 21 H sums,
+// which are compared to tolerance, use FMA.
+template <int kU>
+struct RefLoads {
+  TapLoads r[kU], x[kU], y[kU];
+  float sgx[kU], sgy[kU];  // stale gradients of a patch that is out of the reference view at this level
+  int rec[kU];
+  int vis[kU];
+};
+
+template <bool PN, int kU>
 __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
+  __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartHStride];
   const int b = blockIdx.y;
   const ProbState &st = e.st[b];
@@ -694,6 +735,8 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int loff = (lane >> 3) * sw + (lane & 7);
+  float *rec = sRec[wave];
+  const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
 
   float acc[kHUnique];
 #pragma unroll
@@ -723,51 +766,85 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
     const int base_v = tp.row0 * sw + tp.col0;
     const int vis_v = vis ? 1 : 0;
-
-    // ---- stage 2: patch j, lanes = pixels (utilities.cpp:115-189, odometer.cpp:428-455); two interleaved halves
-    // of the chunk so that consecutive patches (usually frame neighbours) are not in flight together
-    const int half = (cnt + 1) / 2;
-#pragma unroll 2
-    for (int jr = 0; jr < 2 * half; ++jr) {
-      const int j = (jr >> 1) + (jr & 1) * half;
-      if (j >= cnt) continue;  // wave-uniform
-      const float w0 = rlane(tp.w0, j), w1 = rlane(tp.w1, j), w2 = rlane(tp.w2, j), w3 = rlane(tp.w3, j);
-      const int base = rlane(base_v, j);
-      const int pvis = rlane(vis_v, j);
-      float sx[6], sy[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        sx[k] = rlane(cx[k], j);
-        sy[k] = rlane(cy[k], j);
-      }
-      const size_t po = (size_t)(i0 + j) * 64;
-      float gx, gy;
-      if (pvis) {  // wave-uniform branch
-        const TapLoads l0 = taps_issue(pref + base, loff, sw, lane);
-        const TapLoads l1 = taps_issue(pdx + base, loff, sw, lane);
-        const TapLoads l2 = taps_issue(pdy + base, loff, sw, lane);
-        float t = taps_blend(l0, w0, w1, w2, w3, lane);
-        if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188
-        gx = taps_blend(l1, w0, w1, w2, w3, lane);
-        gy = taps_blend(l2, w0, w1, w2, w3, lane);
-        (T + po)[lane] = t;
-        (Gx + po)[lane] = gx;
-        (Gy + po)[lane] = gy;
-      } else {
-        gx = (Gx + po)[lane];
-        gy = (Gy + po)[lane];
-      }
-      float sd[6];
-      sd[0] = gx * sx[0];
-      sd[1] = gy * sy[1];
-#pragma unroll
-      for (int k = 2; k < 6; ++k) sd[k] = gx * sx[k] + gy * sy[k];
-      int jk = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int c = a; c < 6; ++c) acc[jk++] += sd[a] * sd[c];
+    {
+      float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
+      r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
+      r4[1] = make_float4(cx[0], cx[2], cx[3], cx[4]);
+      r4[2] = make_float4(cx[5], cy[1], cy[2], cy[3]);
+      r4[3] = make_float4(cy[4], cy[5], 0.0f, 0.0f);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 2 (utilities.cpp:115-189, odometer.cpp:428-455); patches of a step are nsteps apart
+    const int nsteps = (cnt + kU - 1) / kU;
+    auto issue = [&](RefLoads<kU> &L, int sidx) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int jraw = sidx + u * nsteps;
+        const int jj = min(jraw, cnt - 1);
+        L.rec[u] = (jraw < cnt) ? jj : -1;
+        const int base = rlane(base_v, jj);
+        L.vis[u] = rlane(vis_v, jj);
+        if (L.vis[u]) {  // wave-uniform
+          L.r[u] = taps_issue(pref + base, loff, sw, lane);
+          L.x[u] = taps_issue(pdx + base, loff, sw, lane);
+          L.y[u] = taps_issue(pdy + base, loff, sw, lane);
+        } else {
+          const size_t po = (size_t)(i0 + jj) * 64;
+          L.sgx[u] = (Gx + po)[lane];
+          L.sgy[u] = (Gy + po)[lane];
+        }
+      }
+    };
+    auto reduce = [&](const RefLoads<kU> &L) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (L.rec[u] < 0) continue;  // wave-uniform
+        const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
+                     k2 = rec4[L.rec[u] * 4 + 3];
+        float gx, gy;
+        if (L.vis[u]) {
+          float t = taps_blend(L.r[u], w.x, w.y, w.z, w.w, lane);
+          if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188
+          gx = taps_blend(L.x[u], w.x, w.y, w.z, w.w, lane);
+          gy = taps_blend(L.y[u], w.x, w.y, w.z, w.w, lane);
+          const size_t po = (size_t)(i0 + L.rec[u]) * 64;
+          (T + po)[lane] = t;
+          (Gx + po)[lane] = gx;
+          (Gy + po)[lane] = gy;
+        } else {
+          gx = L.sgx[u];
+          gy = L.sgy[u];
+        }
+        {
+#pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
+          float sd[6];
+          sd[0] = gx * k0.x;
+          sd[1] = gy * k1.y;
+          sd[2] = gx * k0.y + gy * k1.z;
+          sd[3] = gx * k0.z + gy * k1.w;
+          sd[4] = gx * k0.w + gy * k2.x;
+          sd[5] = gx * k1.x + gy * k2.y;
+          int jk = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) acc[jk++] += sd[a] * sd[c];
+        }
+      }
+    };
+    RefLoads<kU> A, B;
+    issue(A, 0);
+    for (int sidx = 0; sidx < nsteps; sidx += 2) {
+      if (sidx + 1 < nsteps) issue(B, sidx + 1);
+      reduce(A);
+      if (sidx + 2 < nsteps) issue(A, sidx + 2);
+      if (sidx + 1 < nsteps) reduce(B);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 
 #pragma unroll
@@ -913,10 +990,14 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
   int nblk = gridx;
   if (e.P == 8 && !(variant & 2)) {
     nblk = gridx8;
+    const dim3 g8(gridx8, e.B);
+    const int ku = (variant >> 6) & 3;  // experiments: patches per pipeline step of the setup kernel
     if (e.dopatchnorm)
-      hipLaunchKernelGGL(k_ref8<true>, dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_ref8<true, 1>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (ku == 1)
+      hipLaunchKernelGGL((k_ref8<false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL(k_ref8<false>, dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_ref8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
     hipLaunchKernelGGL(k_ref_level<4>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
@@ -933,10 +1014,17 @@ void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, i
   int nblk = gridx;
   if (e.P == 8 && !(variant & 2)) {
     nblk = gridx8;
+    const dim3 g8(gridx8, e.B);
+    // patches per pipeline step: 4 measured best (sweep in profiles/r01_notes.md); variant bits 4-5 select others
+    const int ku = (variant >> 4) & 3;
     if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_iter8<true>), dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<true, 2>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (ku == 1)
+      hipLaunchKernelGGL((k_iter8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (ku == 2)
+      hipLaunchKernelGGL((k_iter8<false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL((k_iter8<false>), dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<false, 4>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
     hipLaunchKernelGGL((k_iter<4>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else

@@ -204,9 +204,13 @@ template <int N> ICTR_HD void lu_solve(const float *Hin, const float *bin, float
   }
 }
 
-// Same algorithm with every runtime-indexed array in caller-provided storage (LDS on the device): A (N*N, destroyed),
-// b (N, read), c (N scratch), piv (2N ints scratch). Bit-identical to lu_solve.
-template <int N> ICTR_HD void lu_solve_ws(float *A, const float *bin, float *x, float *c, int *piv) {
+// The same algorithm in two halves, every runtime-indexed array in caller-provided storage (LDS on the device).
+// H is constant during the Gauss-Newton iterations of one pyramid level, so the device factors it once per level
+// and only substitutes per iteration; the arithmetic (and therefore every bit of the result) is that of lu_solve.
+//   lu_factor_ws: A (N*N) is overwritten with the LU factors; piv gets N row + N column transpositions;
+//                 info[0] = number of non-zero pivots, info[1] = rank (Eigen threshold eps*N*|maxpivot|).
+//   lu_apply_ws : x = solve with the stored factors; c is N floats of workspace.
+template <int N> ICTR_HD void lu_factor_ws(float *A, int *piv, int *info) {
   int *rowsw = piv, *colsw = piv + N;
   int nonzero = N;
   float maxpiv = 0.0f;
@@ -249,11 +253,21 @@ template <int N> ICTR_HD void lu_solve_ws(float *A, const float *bin, float *x, 
         for (int r = k + 1; r < N; ++r) A[r * N + cc] -= A[r * N + k] * A[k * N + cc];
     }
   }
+  int rank = 0;
+  if (nonzero > 0) {
+    const float thr = maxpiv * (1.1920929e-07f * N);
+    for (int i = 0; i < nonzero; ++i) rank += (fabsf(A[i * N + i]) > thr) ? 1 : 0;
+  }
+  info[0] = nonzero;
+  info[1] = rank;
+}
+
+template <int N>
+ICTR_HD void lu_apply_ws(const float *A, const int *piv, const int *info, const float *bin, float *x, float *c) {
+  const int *rowsw = piv, *colsw = piv + N;
+  const int nonzero = info[0], rank = info[1];
   for (int i = 0; i < N; ++i) x[i] = 0.0f;
   if (nonzero == 0) return;
-  const float thr = maxpiv * (1.1920929e-07f * N);
-  int rank = 0;
-  for (int i = 0; i < nonzero; ++i) rank += (fabsf(A[i * N + i]) > thr) ? 1 : 0;
   for (int i = 0; i < N; ++i) c[i] = bin[i];
   for (int k = 0; k < N; ++k) {
     const int r = rowsw[k];
