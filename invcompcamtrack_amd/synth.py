@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["se3_exp", "texture", "make_scene", "grid_points"]
+__all__ = ["se3_exp", "texture", "make_scene", "make_sequence", "grid_points"]
 
 
 def se3_exp(p):
@@ -111,3 +111,41 @@ def make_scene(w, h, n_points=None, *, grid_step=None, seed=42, depth=10.0, p_a=
     return dict(img_a=img_a.astype(dtype), img_b=img_b.astype(dtype), pts3d=np.ascontiguousarray(Xw),
                 px_a=px, p_a=p_a, p_b=p_b, fc=fc.astype(np.float32), cc=cc.astype(np.float32),
                 wh=np.array([w, h], np.int32))
+
+
+def _render(tex, w, h, fc, cc, G_ref, G_k, depth):
+    """Frame seen through pose G_k of the textured plane Z = depth of the REFERENCE camera G_ref (exact ray/plane
+    intersection, no resampling)."""
+    Ra, ta = G_ref[:, :3], G_ref[:, 3]
+    Rb, tb = G_k[:, :3], G_k[:, 3]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    R = Rb @ Ra.T
+    t = tb - R @ ta
+    rx, ry = (xx - cc[0]) / fc[0], (yy - cc[1]) / fc[1]
+    n_rt = R[:, 2]
+    lam = (depth + n_rt @ t) / (n_rt[0] * rx + n_rt[1] * ry + n_rt[2])
+    XB = np.stack([lam * rx, lam * ry, lam], 0).reshape(3, -1)
+    XA = R.T @ (XB - t[:, None])
+    return tex(XA[0] / XA[2] * fc[0] + cc[0], XA[1] / XA[2] * fc[1] + cc[1]).reshape(h, w)
+
+
+def make_sequence(w, h, poses, ref_index, n_points, *, seed=42, depth=10.0, fc=None, cc=None, tex_seed=1234,
+                  quantize=True, margin=24.0):
+    """A multi-frame version of make_scene for the run_track_nposes workload: frames[k] is the plane seen through
+    poses[k]; the 3-D points are pixels of frame ref_index lifted to the plane (world coordinates) together with their
+    2-D positions in that frame. quantize=True rounds to 8-bit grey levels like an image file would."""
+    rng = np.random.default_rng(seed)
+    fc = np.array([1000.0, 1200.0]) * (w / 1280.0) if fc is None else np.asarray(fc, np.float64)
+    cc = np.array([20.0, 30.0]) * (w / 1280.0) + np.array([w, h]) / 2.0 if cc is None else np.asarray(cc, np.float64)
+    tex = _Texture(tex_seed)
+    Gs = [se3_exp(p) for p in poses]
+    frames = []
+    for G in Gs:
+        f = _render(tex, w, h, fc, cc, Gs[ref_index], G, depth)
+        frames.append((np.round(f) if quantize else f).astype(np.float32))
+    px = np.stack([rng.uniform(margin, w - margin, n_points), rng.uniform(margin, h - margin, n_points)], 1)
+    Ra, ta = Gs[ref_index][:, :3], Gs[ref_index][:, 3]
+    XA = np.stack([(px[:, 0] - cc[0]) / fc[0] * depth, (px[:, 1] - cc[1]) / fc[1] * depth, np.full(n_points, depth)], 0)
+    Xw = Ra.T @ (XA - ta[:, None])
+    return dict(frames=frames, pts3d=np.ascontiguousarray(Xw.T), px_ref=px, fc=fc.astype(np.float32),
+                cc=cc.astype(np.float32), wh=np.array([w, h], np.int32))

@@ -1,0 +1,160 @@
+"""World-size-2 (gloo, CPU) test of the sharded Gauss-Newton loop: points split over ranks, H all-reduced once per
+level and b once per iteration (invcompcamtrack_amd/dist.py). No GPU here, so the per-rank accumulate / finish steps
+are played by a NumPy stand-in built on the oracle's element-wise pieces (test infrastructure); what is under test is
+the partition, the collective sequence and that every rank ends with the same pose as the unsharded oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class NumpyShardEngine:
+    """begin / level_accumulate / level_finish / iter_accumulate / iter_finish on one shard of the points, with the
+    reduction buffer laid out like the HIP engine's (27 floats: 21 H upper triangle + 6 b)."""
+
+    def __init__(self, O, N, sc, lo, hi, lv_f, psz, maxiter):
+        self.O, self.N = O, N
+        self.pts = sc["pts3d"][:, lo:hi].astype(np.float32)
+        self.pa, self.pb = O.Pyramid(sc["img_a"], lv_f, psz), O.Pyramid(sc["img_b"], lv_f, psz)
+        op = O.make_op(lv_f, 0, psz, maxiter, 0.0, 0, 0, max(hi - lo, 4))
+        self.cam = O.Tracker(op, sc["fc"], sc["cc"], sc["wh"])
+        self.psz = psz
+        self.p = sc["p_a"].astype(np.float32)
+        self.red = np.zeros(27, np.float32)
+
+    def begin(self):
+        G0 = self.N.exp_se3(self.p)
+        X, Y, Z = self.pts
+        _, _, self.Xc, self.Yc, self.Zc = self.N.project(G0, X, Y, Z, np.float32(1), np.float32(1), np.float32(0), np.float32(0))
+        self.G0 = G0
+
+    def _cam(self, sl):
+        return [np.float32(self.cam.cam_get(k, sl)) for k in range(4)]
+
+    def level_accumulate(self, sl):
+        N, P = self.N, self.psz
+        fx, fy, cx, cy = self._cam(sl)
+        X, Y, Z = self.pts
+        mx, my, _, _, _ = N.project(self.G0, X, Y, Z, fx, fy, cx, cy)
+        self.T = N.patches(self.pa.img[sl], mx, my, P)
+        Gx, Gy = N.patches(self.pa.dx[sl], mx, my, P), N.patches(self.pa.dy[sl], mx, my, P)
+        cxk, cyk = N.sd_coefs(self.Xc, self.Yc, self.Zc, fx, fy)
+        sd = Gx[:, None] * cxk[:, :, None, None] + Gy[:, None] * cyk[:, :, None, None]
+        sd[:, 0], sd[:, 1] = Gx * cxk[:, 0, None, None], Gy * cyk[:, 1, None, None]
+        self.sd = sd
+        sdf = sd.reshape(len(X), 6, -1).astype(np.float64)
+        H = np.einsum("kip,kjp->ij", sdf, sdf) if len(X) else np.zeros((6, 6))
+        self.red[:21] = H[np.triu_indices(6)].astype(np.float32)
+
+    def level_finish(self, sl):
+        H = np.zeros((6, 6), np.float32)
+        H[np.triu_indices(6)] = self.red[:21]
+        self.H = H + np.triu(H, 1).T
+        self.red[:] = 0
+
+    def iter_accumulate(self, sl):
+        N = self.N
+        fx, fy, cx, cy = self._cam(sl)
+        X, Y, Z = self.pts
+        nx, ny, _, _, _ = N.project(N.exp_se3(self.p), X, Y, Z, fx, fy, cx, cy)
+        r = self.T - N.patches(self.pb.img[sl], nx, ny, self.psz)
+        b = (self.sd * r[:, None]).reshape(len(X), 6, -1).astype(np.float64).sum((0, 2)) if len(X) else np.zeros(6)
+        self.red[21:] = b.astype(np.float32)
+
+    def iter_finish(self, sl):
+        self.p = self.p + self.O.solve6(self.H, self.red[21:].copy())
+        self.red[21:] = 0
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from invcompcamtrack_amd import synth
+    from invcompcamtrack_amd.dist import run_sharded_levels, shard_slices
+    from oracle import np_oracle as N
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sc = synth.make_scene(320, 240, n_points=61, seed=12, margin=40.0)  # odd count: unbalanced shards
+    lo, hi = shard_slices(61, world)[rank]
+    lv_f, psz, maxiter = 2, 8, 4
+    eng = NumpyShardEngine(O, N, sc, lo, hi, lv_f, psz, maxiter)
+    calls = []
+
+    def allreduce():
+        t = torch.from_numpy(eng.red)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # in place on the engine's buffer, like the RCCL path
+        calls.append(1)
+
+    op = O.make_op(lv_f, 0, psz, maxiter, 0.0, 0, 0, 64)
+    run_sharded_levels(eng, op, allreduce)
+    q.put((rank, eng.p.copy(), len(calls), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_loop_two_ranks_gloo(oracle):
+    import torch.multiprocessing as mp
+    from invcompcamtrack_amd import synth
+    from invcompcamtrack_amd.dist import shard_slices
+    assert shard_slices(61, 2) == [(0, 31), (31, 61)] and shard_slices(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, p0, n0, s0), (r1, p1, n1, s1) = res
+    assert np.array_equal(p0, p1)                      # identical bits on both ranks: no broadcast needed
+    assert n0 == n1 == 3 * (1 + 4)                     # one all-reduce per level + one per iteration
+    assert s0 == (0, 31) and s1 == (31, 61)
+    # unsharded oracle on the same inputs
+    sc = synth.make_scene(320, 240, n_points=61, seed=12, margin=40.0)
+    op = oracle.make_op(2, 0, 8, 4, 0.0, 0, 0, 61)
+    tr = oracle.Tracker(op, sc["fc"], sc["cc"], sc["wh"])
+    tr.set3dpoints(sc["pts3d"].copy())
+    tr.setpose(sc["p_a"], oracle.Pyramid(sc["img_a"], 2, 8), oracle.Pyramid(sc["img_b"], 2, 8))
+    tr.trackpose()
+    assert np.allclose(p0, tr.pose_p(), atol=2e-5)
+
+
+def test_global_norm_matches_single_rank_formula():
+    """dist.global_norm == the reference's mean / mean squared radius (odometer.cpp:193-214) over all ranks' points."""
+    from invcompcamtrack_amd.dist import global_norm
+
+    class FakeDist:  # two "ranks" summed by hand
+        def __init__(self, other):
+            self.other = other
+
+        def all_reduce(self, t, group=None):
+            t += self.other.pop(0)
+
+        def get_backend(self, group=None):
+            return "gloo"
+
+    import torch
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(3, 10)) + 5, rng.normal(size=(3, 7)) - 2
+    allp = np.concatenate([a, b], 1)
+    mean = allp.mean(1)
+    other = [torch.tensor([b[0].sum(), b[1].sum(), b[2].sum(), 7.0], dtype=torch.float64),
+             torch.tensor([float(((b - mean[:, None]) ** 2).sum())], dtype=torch.float64)]
+    m, v = global_norm(a, dist=FakeDist(other))
+    assert np.allclose(m, mean) and np.isclose(v, ((allp - mean[:, None]) ** 2).sum(0).mean())
