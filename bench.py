@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (bit0: LDS-staged current-frame window)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 rehearsal on ONE GPU: all ranks use cuda:0 and the 27*B floats are all-reduced through "
+                         "host memory with gloo (same kernels, same phase sequence; numbers are not a benchmark)")
     return ap.parse_args()
 
 
@@ -117,7 +120,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    if world > 1:
+    if world > 1 and args.rehearse_gloo:
+        import torch.distributed as dist
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    elif world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -134,11 +142,12 @@ def main():
     tracker = None
     if world > 1:
         from invcompcamtrack_amd.dist import ShardedTracker
-        tracker = ShardedTracker(batch)
+        tracker = ShardedTracker(batch, staged=args.rehearse_gloo)
     elif not args.no_events:
         batch.set_timing(True)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -168,7 +177,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
