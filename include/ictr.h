@@ -199,6 +199,9 @@ int ictr_batch_read_buffer(ictr_batch *b, int64_t problem, int which, float *hos
  * After the track has completed: ms_setup[l], ms_iters[l] for l in 0..lv_f (0 for levels not run). */
 int ictr_batch_set_timing(ictr_batch *b, int enable);
 int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters);
+/* ms_kernel[l]: summed duration of the level's maxiter accumulate-kernel launches ALONE (events around each launch,
+ * excluding the tail kernels and the gaps) -- the figure comparable with rocprofv3 --kernel-trace --stats */
+int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel);
 
 /* ---- distributed (points sharded over ranks): split phases so the caller can all-reduce ----
  * The normal-equation block lives in a caller-visible device buffer: per problem 21 floats of H

@@ -26,6 +26,8 @@ void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
 void launch_ref_level(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
 void launch_level_finish(const EngineDev &, hipStream_t);
 void launch_iter(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
+void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
+void launch_iter_tail(const EngineDev &, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, hipStream_t);
 }  // namespace ictr
 
@@ -529,12 +531,15 @@ struct ictr_batch {
   bool timing = false;
   std::vector<hipEvent_t> ev;  // 3 per level
   std::vector<char> ev_used;
+  std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
+  int evk_iters = 0;
   float *d_red_own = nullptr;
 };
 
 static void batch_free(ictr_batch *b) {
   if (!b) return;
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->evk) (void)hipEventDestroy(e);
   b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
@@ -838,16 +843,24 @@ extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
   return ICTR_OK;
 }
 
+// split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket
+// the accumulate kernel alone
 static int enqueue_levels(ictr_batch *b) {
   const EngineDev e = engine_dev(b);
   if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
+  const int mi = b->op->maxiter;
+  const bool tk = b->timing && (int)b->evk.size() >= 2 * b->nlev * mi && mi <= b->evk_iters;
   for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
     const LevelCam lc = level_cam(b->cam, sl);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], b->stream));
     launch_ref_level(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], b->stream));
-    for (int it = 0; it < b->op->maxiter; ++it)
-      launch_iter(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+    for (int it = 0; it < mi; ++it) {
+      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it)], b->stream));
+      launch_iter_main(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it) + 1], b->stream));
+      launch_iter_tail(e, sl, b->gridx, b->variant, b->gridx8, b->stream);
+    }
     if (b->timing) {
       HIPCHK(hipEventRecord(b->ev[3 * sl + 2], b->stream));
       b->ev_used[sl] = 1;
@@ -870,6 +883,9 @@ extern "C" int ictr_batch_set_timing(ictr_batch *b, int enable) {
     b->ev.resize(3 * b->nlev);
     b->ev_used.assign(b->nlev, 0);
     for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
+    b->evk_iters = std::max(1, b->op->maxiter);
+    b->evk.resize((size_t)2 * b->nlev * b->evk_iters);
+    for (auto &e : b->evk) HIPCHK(hipEventCreate(&e));
   }
   b->timing = enable != 0;
   return ICTR_OK;
@@ -883,6 +899,22 @@ extern "C" int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float 
     if (!b->ev_used[l]) continue;
     HIPCHK(hipEventElapsedTime(&ms_setup[l], b->ev[3 * l + 0], b->ev[3 * l + 1]));
     HIPCHK(hipEventElapsedTime(&ms_iters[l], b->ev[3 * l + 1], b->ev[3 * l + 2]));
+  }
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel) {
+  if (!b || !ms_kernel) return fail(ICTR_ERR_INVALID, "get_kernel_times: NULL argument");
+  if (b->evk.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const int mi = std::min(b->op->maxiter, b->evk_iters);
+  for (int l = 0; l < b->nlev; ++l) {
+    ms_kernel[l] = 0.0f;
+    if (!b->ev_used[l]) continue;
+    for (int it = 0; it < mi; ++it) {
+      float ms = 0.0f;
+      HIPCHK(hipEventElapsedTime(&ms, b->evk[2 * (l * b->evk_iters + it)], b->evk[2 * (l * b->evk_iters + it) + 1]));
+      ms_kernel[l] += ms;
+    }
   }
   return ICTR_OK;
 }

@@ -581,7 +581,7 @@ struct PatchLoads {  // raw load results of one stage-2 step of kU patches (cons
   int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
 };
 
-template <bool PN, int kU>
+template <bool PN, int kU, bool NT = true>
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartBStride];
@@ -652,9 +652,15 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         L.rec[u] = (jraw < cnt) ? jj : -1;
         const int base = rlane(base_v, jj);
         const size_t po = (size_t)(i0 + jj) * 64;  // wave-uniform: scalar base + 32-bit lane offset
-        L.t[u] = (T + po)[lane];
-        L.gx[u] = (Gx + po)[lane];
-        L.gy[u] = (Gy + po)[lane];
+        if constexpr (NT) {  // streamed once per launch: keep them from evicting the (re-used) frame lines
+          L.t[u] = __builtin_nontemporal_load(T + po + lane);
+          L.gx[u] = __builtin_nontemporal_load(Gx + po + lane);
+          L.gy[u] = __builtin_nontemporal_load(Gy + po + lane);
+        } else {
+          L.t[u] = (T + po)[lane];
+          L.gx[u] = (Gx + po)[lane];
+          L.gy[u] = (Gy + po)[lane];
+        }
         L.cur[u] = taps_issue(cur + base, loff, sw, lane);
       }
     };
@@ -714,7 +720,7 @@ struct RefLoads {
   int vis[kU];
 };
 
-template <bool PN, int kU>
+template <bool PN, int kU, bool NT = true>
 __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartHStride];
@@ -811,9 +817,15 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
           gx = taps_blend(L.x[u], w.x, w.y, w.z, w.w, lane);
           gy = taps_blend(L.y[u], w.x, w.y, w.z, w.w, lane);
           const size_t po = (size_t)(i0 + L.rec[u]) * 64;
-          (T + po)[lane] = t;
-          (Gx + po)[lane] = gx;
-          (Gy + po)[lane] = gy;
+          if constexpr (NT) {  // 400 MB written once per level: do not let them push the pyramid planes out of L2
+            __builtin_nontemporal_store(t, T + po + lane);
+            __builtin_nontemporal_store(gx, Gx + po + lane);
+            __builtin_nontemporal_store(gy, Gy + po + lane);
+          } else {
+            (T + po)[lane] = t;
+            (Gx + po)[lane] = gx;
+            (Gy + po)[lane] = gy;
+          }
         } else {
           gx = L.sgx[u];
           gy = L.sgy[u];
@@ -996,6 +1008,8 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
       hipLaunchKernelGGL((k_ref8<true, 1>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
       hipLaunchKernelGGL((k_ref8<false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (ku == 2)
+      hipLaunchKernelGGL((k_ref8<false, 1, false>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal stores
     else
       hipLaunchKernelGGL((k_ref8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
@@ -1007,15 +1021,13 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
 void launch_level_finish(const EngineDev &e, hipStream_t s) {
   hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e);
 }
-// steps 7-10 of one Gauss-Newton iteration for every problem: accumulate kernel + per-problem tail
-void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
-                 hipStream_t s) {
+// steps 7-9a of one Gauss-Newton iteration for every problem (the accumulate kernel) ...
+void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
+                      hipStream_t s) {
   const dim3 blk(kBlock);
-  int nblk = gridx;
   if (e.P == 8 && !(variant & 2)) {
-    nblk = gridx8;
     const dim3 g8(gridx8, e.B);
-    // patches per pipeline step: 4 measured best (sweep in profiles/r01_notes.md); variant bits 4-5 select others
+    // patches per pipeline step: 4 measured best (profiles/r01_notes.md); variant bits 4-5 select others for A/B
     const int ku = (variant >> 4) & 3;
     if (e.dopatchnorm)
       hipLaunchKernelGGL((k_iter8<true, 2>), g8, blk, 0, s, e, lc, level, cpw);
@@ -1023,13 +1035,24 @@ void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, i
       hipLaunchKernelGGL((k_iter8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 2)
       hipLaunchKernelGGL((k_iter8<false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (ku == 3)
+      hipLaunchKernelGGL((k_iter8<false, 4, false>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal loads
     else
       hipLaunchKernelGGL((k_iter8<false, 4>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
     hipLaunchKernelGGL((k_iter<4>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
     hipLaunchKernelGGL((k_iter<0>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
-  hipLaunchKernelGGL(k_iter_tail, dim3(e.B), blk, 0, s, e, level, nblk);
+}
+// ... and steps 9b-10 (one workgroup per problem)
+void launch_iter_tail(const EngineDev &e, int level, int gridx, int variant, int gridx8, hipStream_t s) {
+  const int nblk = (e.P == 8 && !(variant & 2)) ? gridx8 : gridx;
+  hipLaunchKernelGGL(k_iter_tail, dim3(e.B), dim3(kBlock), 0, s, e, level, nblk);
+}
+void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
+                 hipStream_t s) {
+  launch_iter_main(e, lc, level, gridx, variant, cpw, gridx8, s);
+  launch_iter_tail(e, level, gridx, variant, gridx8, s);
 }
 void launch_iter_finish(const EngineDev &e, int level, hipStream_t s) {
   hipLaunchKernelGGL(k_iter_finish, dim3((e.B + 63) / 64), dim3(64), 0, s, e, level);

@@ -388,6 +388,12 @@ class TrackBatch:
         check(_lib.load().ictr_batch_get_level_times(self._h, fp(a), fp(b)))
         return a, b
 
+    def kernel_times(self):
+        """ms per level spent in the accumulate-kernel launches alone (comparable with rocprofv3 --stats)."""
+        a = np.zeros(self.op.lv_f + 1, np.float32)
+        check(_lib.load().ictr_batch_get_kernel_times(self._h, fp(a)))
+        return a
+
     def set_reduction_buffer(self, dev_ptr):
         check(_lib.load().ictr_batch_set_reduction_buffer(self._h, C.c_void_p(dev_ptr or 0)))
 

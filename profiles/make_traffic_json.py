@@ -20,6 +20,9 @@ if "FETCH_SIZE" in rows:
     fetch0 = out["FETCH_SIZE_mean_per_level"][0] * 1024 * 2   # KiB -> B, gfx950 x2 correction
     write0 = out.get("WRITE_SIZE_mean_per_level", [0])[0] * 1024
     out["hbm_bytes_per_launch_level0"] = fetch0 + write0
+    fm = out["FETCH_SIZE_mean_per_level"]
+    wm = out.get("WRITE_SIZE_mean_per_level", [0, 0, 0])
+    out["hbm_bytes_per_launch_mean"] = sum(f * 2048 + w * 1024 for f, w in zip(fm, wm)) / len(fm)
     out["note"] = "FETCH_SIZE x 1024 x 2 (gfx950 coalesced-read correction) + WRITE_SIZE x 1024; 4-byte-per-lane loads are 'uncalibrated' per the guide, so read this as an upper bound of ~2x the raw counter"
 json.dump(out, open("profiles/traffic_r01.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
