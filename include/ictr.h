@@ -217,6 +217,16 @@ int ictr_batch_level_finish(ictr_batch *b, int level);      /* adopt (reduced) H
 int ictr_batch_iter_accumulate(ictr_batch *b, int level);   /* steps 7-9a -> local b in red[] */
 int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on the (reduced) b */
 
+/* ------------------------------------------------------------------ flow producer for the misc_src/run_*OF* drivers
+ * Those drivers shell out to an external optical-flow binary that is not in the reference repository
+ * (misc_src/run_test_OF_track.py:90-108). ictr_patchflow is the in-tree replacement: K independent psz x psz patches
+ * (psz <= 32), each with its own 2-parameter translation, pyramidal inverse-compositional Lucas-Kanade with
+ * util_getPatch's sampling convention; one wave64 per patch runs every level and iteration inside one launch.
+ * pts: host SoA x[K] y[K] at level 0 in frame A; out: host SoA positions in frame B (NaN when lost);
+ * status (optional) 1/0; iters (optional) executed iterations. Build-defined algorithm: no reference pins it. */
+int ictr_patchflow(const ictr_pyramid *pyr_a, const ictr_pyramid *pyr_b, const float *pts, int64_t K, int psz, int lv_f,
+                   int lv_l, int maxiter, float eps, float *out, int *status, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

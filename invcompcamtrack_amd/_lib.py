@@ -121,6 +121,7 @@ SIGNATURES = {
     "ictr_batch_level_finish": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_accumulate": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_finish": (C.c_int, [VP, C.c_int]),
+    "ictr_patchflow": (C.c_int, [VP, VP, FP, I64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, IP, IP]),
 }
 
 _lib = None

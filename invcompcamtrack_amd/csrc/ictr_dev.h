@@ -74,4 +74,21 @@ struct EngineDev {
   DevTrace trace;
 };
 
+// per-patch translation IC-LK (ictr_patchflow.hip)
+struct PFLevel {
+  const float *a, *ax, *ay, *b;  // frame A image + gradients, frame B image (padded planes)
+  int sw;
+  float swo, sho, scale;  // unpadded size, 0.5^level
+};
+struct PFArgs {
+  PFLevel lv[16];
+  int lv_f, lv_l, P, maxiter, K;
+  float eps2;        // stop when |dp|^2 < eps2
+  float min_det;     // relative conditioning threshold of the 2x2 system
+  const float *pts;  // SoA x[K] y[K] at level 0
+  float *out;        // SoA x'[K] y'[K] at level 0 (NaN when lost)
+  int *status;       // 1 tracked, 0 lost
+  int *iters;        // executed iterations (all levels)
+};
+
 }  // namespace ictr

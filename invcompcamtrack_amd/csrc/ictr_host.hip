@@ -31,6 +31,10 @@ void launch_iter_tail(const EngineDev &, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, hipStream_t);
 }  // namespace ictr
 
+namespace ictr {
+void launch_patchflow(const PFArgs &, hipStream_t);
+}  // namespace ictr
+
 using namespace ictr;
 
 // ---------------------------------------------------------------- errors
@@ -1093,5 +1097,58 @@ extern "C" int ictr_odometer_get_norm(const ictr_odometer *o, double *meanshift3
   if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
   if (meanshift3) memcpy(meanshift3, o->b->probs[0].meanshift, sizeof(double) * 3);
   if (varval) *varval = o->b->probs[0].varval;
+  return ICTR_OK;
+}
+
+// ---------------------------------------------------------------- per-patch translation IC-LK (flow producer)
+extern "C" int ictr_patchflow(const ictr_pyramid *pa, const ictr_pyramid *pb, const float *pts, int64_t K, int psz,
+                              int lv_f, int lv_l, int maxiter, float eps, float *out, int *status, int *iters) {
+  if (!pa || !pb || K < 0 || (K > 0 && (!pts || !out)) || psz < 1 || psz > 32 || lv_l < 0 || lv_f < lv_l || maxiter < 0)
+    return fail(ICTR_ERR_INVALID, "patchflow: bad arguments (psz must be 1..32)");
+  if (lv_f >= pa->nlev || lv_f >= pb->nlev || lv_f > 15)
+    return fail(ICTR_ERR_INVALID, "patchflow: pyramids have fewer than lv_f+1 levels");
+  if (!pa->getgrad) return fail(ICTR_ERR_INVALID, "patchflow: the first pyramid needs gradients");
+  if (pa->pad < psz || pb->pad < psz) return fail(ICTR_ERR_INVALID, "patchflow: pyramid padding must be >= psz");
+  for (int l = lv_l; l <= lv_f; ++l)
+    if (pa->w[l] != pb->w[l] || pa->h[l] != pb->h[l] || pa->sw[l] != pb->sw[l])
+      return fail(ICTR_ERR_INVALID, "patchflow: the two pyramids differ in size at level %d", l);
+  if (K == 0) return ICTR_OK;
+  if (int rc = need_device()) return rc;
+  PFArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int l = lv_l; l <= lv_f; ++l) {
+    a.lv[l].a = pa->img[l];
+    a.lv[l].ax = pa->dx[l];
+    a.lv[l].ay = pa->dy[l];
+    a.lv[l].b = pb->img[l];
+    a.lv[l].sw = pa->sw[l];
+    a.lv[l].swo = (float)pa->w[l];
+    a.lv[l].sho = (float)pa->h[l];
+    a.lv[l].scale = (float)(1 / pow(2, l));
+  }
+  a.lv_f = lv_f;
+  a.lv_l = lv_l;
+  a.P = psz;
+  a.maxiter = maxiter;
+  a.K = (int)K;
+  a.eps2 = eps * eps;
+  a.min_det = 1e-4f;
+  float *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, sizeof(float) * 6 * K));
+  float *d_pts = d, *d_out = d + 2 * K;
+  int *d_status = reinterpret_cast<int *>(d + 4 * K), *d_iters = reinterpret_cast<int *>(d + 5 * K);
+  a.pts = d_pts;
+  a.out = d_out;
+  a.status = d_status;
+  a.iters = d_iters;
+  hipError_t e = hipMemcpy(d_pts, pts, sizeof(float) * 2 * K, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_patchflow(a, nullptr);
+    e = hipMemcpy(out, d_out, sizeof(float) * 2 * K, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && status) e = hipMemcpy(status, d_status, sizeof(int) * K, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && iters) e = hipMemcpy(iters, d_iters, sizeof(int) * K, hipMemcpyDeviceToHost);
+  }
+  hipFree(d);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "patchflow failed: %s", hipGetErrorString(e));
   return ICTR_OK;
 }

@@ -1,0 +1,77 @@
+"""The in-tree flow producer (per-patch translation IC-LK) against its NumPy oracle, and the re-created
+run_OF_point_track loop feeding classoftrack.oftrack. Build-defined algorithm: parity unpinned by the reference."""
+import numpy as np
+import pytest
+
+import invcompcamtrack_amd as ic
+from invcompcamtrack_amd import patchflow as pf
+from invcompcamtrack_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(w, h, seed, dp):
+    sc = synth.make_scene(w, h, n_points=10, seed=seed, dp_gt=np.asarray(dp, float))
+    return sc
+
+
+@pytest.mark.parametrize("psz,lv_f", [(8, 2), (15, 3), (31, 3)])
+def test_track_points_matches_numpy_oracle(oracle, psz, lv_f):
+    from oracle import np_patchflow as NP
+    sc = _pair(256, 224, 4, [0.02, -0.012, 0.01, 0.002, -0.001, 0.003])
+    rng = np.random.default_rng(psz)
+    pts = np.concatenate([rng.uniform([20, 20], [236, 204], (60, 2)),
+                          np.array([[0.0, 0.0], [255.9, 223.9], [-3.0, 50.0], [np.nan, 5.0], [128.0, 112.0]])]).astype(np.float32)
+    ga, gb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
+    oa, ob = oracle.Pyramid(sc["img_a"], lv_f, psz), oracle.Pyramid(sc["img_b"], lv_f, psz)
+    new_g, ok_g, it_g = pf.track_points(ga, gb, pts, psz=psz, lv_f=lv_f, maxiter=8, eps=0.005)
+    new_o, ok_o, it_o = NP.track_points(oa, ob, pts, psz, lv_f, maxiter=8, eps=0.005)
+    assert np.array_equal(ok_g, ok_o)
+    assert not ok_g[-3] and not ok_g[-2] and np.isnan(new_g[-2]).all()  # outside / NaN inputs are "lost"
+    good = ok_g & ok_o
+    assert good.sum() >= 55
+    assert np.abs(new_g[good] - new_o[good]).max() <= 5e-3       # f32 FMA kernel vs f64-accumulating oracle
+    assert np.abs(it_g[good] - it_o[good]).max() <= 1
+    # it follows the true motion: the plane moves by a few pixels
+    d = new_g[good] - pts[good]
+    assert 0.2 < np.abs(d).mean() < 20
+
+
+def test_identity_gives_zero_flow():
+    sc = _pair(256, 224, 5, [0, 0, 0, 0, 0, 0])
+    g = ic.Pyramid(sc["img_a"], 2, 15)
+    pts = np.random.default_rng(0).uniform([20, 20], [236, 204], (100, 2)).astype(np.float32)
+    new, ok, it = pf.track_points(g, g, pts, psz=15, lv_f=2)
+    assert ok.all() and np.array_equal(new, pts) and np.all(it == 3)  # one iteration per level, dp == 0 exactly
+
+
+def test_forward_backward_consistency_and_oftrack_loop(tmp_path):
+    step = np.array([0.01, -0.006, 0.008, 0.001, -0.0008, 0.0015])
+    base = np.array([0.3, -0.2, 0.5, 0.02, -0.03, 0.01])
+    seq = synth.make_sequence(320, 240, [base + k * step for k in range(5)], 0, 10, seed=2)
+    frames = seq["frames"]
+    pa, pb = ic.Pyramid(frames[0], 3, 15), ic.Pyramid(frames[1], 3, 15)
+    f = pf.dense_flow(pa, pb, step=4, psz=15, lv_f=3)
+    bwd = pf.dense_flow(pb, pa, step=4, psz=15, lv_f=3)
+    assert f.shape == (240, 320, 2) and f.dtype == np.float32 and np.isfinite(f).all()
+    # forward-backward: x + f(x) + b(x + f(x)) ~ x in the interior
+    from invcompcamtrack_amd.classoftrack import func_get_transf_position
+    pts = np.random.default_rng(1).uniform([40, 40], [280, 200], (200, 2))
+    fw = func_get_transf_position(pts, f[:, :, 0], f[:, :, 1])
+    back = func_get_transf_position(fw, bwd[:, :, 0], bwd[:, :, 1])
+    assert np.nanmedian(np.linalg.norm(back - pts, axis=1)) < 0.05
+    corners = pf.good_features(frames[0], 200, 0.001, 5)
+    assert 50 < len(corners) <= 200 and corners.dtype == np.float32
+    d = np.linalg.norm(corners[:, None] - corners[None], axis=2) + 1e9 * np.eye(len(corners))
+    assert d.min() >= 1.0
+    tr = pf.run_OF_point_track(frames, bsize=4, psz=15, lv_f=3, step=4, maxcorners=150,
+                               savefile=str(tmp_path / "tracks.npz"))
+    assert tr.frcounter == 4 and len(tr.tracks) == 4
+    t0 = tr.tracks[0]  # block opened at frame 0, compacted after it left the window of 4
+    assert t0.shape[1:] == (2, 4) and t0.shape[0] > 30 and np.isfinite(t0).all()
+    pt = tr.getpttransfer()
+    assert pt.ndim == 3 and pt.shape[1:] == (2, 2) and pt.shape[0] > 100
+    mv = np.linalg.norm(pt[:, :, 1] - pt[:, :, 0], axis=1)
+    assert 0.1 < np.nanmedian(mv) < 10
+    import os
+    assert os.path.getsize(str(tmp_path / "tracks.npz")) > 1000
