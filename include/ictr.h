@@ -227,6 +227,42 @@ int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on th
 int ictr_patchflow(const ictr_pyramid *pyr_a, const ictr_pyramid *pyr_b, const float *pts, int64_t K, int psz, int lv_f,
                    int lv_l, int maxiter, float eps, float *out, int *status, int *iters);
 
+/* ------------------------------------------------------------------ full-frame parametric alignment (extension)
+ * Inverse-compositional Gauss-Newton alignment of a whole template region under one parametric warp:
+ * model 0 translation (2), 1 SE(2) (3), 2 affine (6), 3 homography (8). These are the warp models BASELINE.json's
+ * configs 1, 2, 3 and 5 name; the reference itself has no such warp (its only warp is the SE(3) reprojection of
+ * 3-D points, odometer.cpp:193-300), so this engine is build-defined: same Gauss-Newton skeleton (template
+ * gradients + Hessian once per level, residual + J^T r per iteration, coarse-to-fine), Baker-Matthews update
+ * M <- M * W(dp)^-1; oracle = oracle/np_icgn.py. nproblems independent frame pairs run in every launch.
+ * Warps cross the boundary as row-major 3x3 matrices in level-0 pixel coordinates (template pixel -> current pixel). */
+typedef struct ictr_icgn ictr_icgn;
+#define ICTR_WARP_TRANSLATION 0
+#define ICTR_WARP_SE2 1
+#define ICTR_WARP_AFFINE 2
+#define ICTR_WARP_HOMOGRAPHY 3
+/* region_xywh: template rectangle at level 0, NULL = the frame minus a 2-pixel rim; eps: stop when |dp| <= eps */
+int ictr_icgn_create(ictr_icgn **out, int model, int w, int h, int lv_f, int lv_l, int maxiter, float eps,
+                     const int *region_xywh, int64_t nproblems);
+void ictr_icgn_destroy(ictr_icgn *g);
+int ictr_icgn_set_stream(ictr_icgn *g, void *hip_stream);
+/* pyramids: lv_f+1 levels, gradients on the template, padding >= 2; borrowed, must outlive the run */
+int ictr_icgn_set_frames(ictr_icgn *g, int64_t problem, const ictr_pyramid *tmpl, const ictr_pyramid *cur);
+int ictr_icgn_set_warp(ictr_icgn *g, int64_t problem, const double *M9); /* initial warp, NULL = identity */
+int ictr_icgn_set_timing(ictr_icgn *g, int enable);
+int ictr_icgn_run_async(ictr_icgn *g); /* all levels, all iterations, no host synchronisation */
+/* M9_out: nproblems*9; iters: nproblems; last_dp: nproblems*8 (any may be NULL). Synchronises the stream. */
+int ictr_icgn_get_results(ictr_icgn *g, double *M9_out, int *iters, float *last_dp);
+int ictr_icgn_get_kernel_times(ictr_icgn *g, float *ms_per_level); /* summed k_icgn_iter time per level */
+/* row-band sharding (BASELINE config 5): each rank owns template rows [row_lo, row_hi) at level 0 and all-reduces
+ * the 44-float record per problem (36 upper-triangle H + 8 b) between the accumulate and finish phases. */
+int ictr_icgn_set_rows(ictr_icgn *g, int row_lo, int row_hi);
+int ictr_icgn_enable_sharding(ictr_icgn *g, int enable, float *red_dev /* nproblems*44 floats or NULL */);
+int ictr_icgn_begin(ictr_icgn *g);
+int ictr_icgn_hess_accumulate(ictr_icgn *g, int level);
+int ictr_icgn_hess_finish(ictr_icgn *g, int level);
+int ictr_icgn_iter_accumulate(ictr_icgn *g, int level);
+int ictr_icgn_iter_finish(ictr_icgn *g, int level);
+
 #ifdef __cplusplus
 }
 #endif

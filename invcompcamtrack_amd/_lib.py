@@ -122,6 +122,23 @@ SIGNATURES = {
     "ictr_batch_iter_accumulate": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_finish": (C.c_int, [VP, C.c_int]),
     "ictr_patchflow": (C.c_int, [VP, VP, FP, I64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, IP, IP]),
+    "ictr_icgn_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, IP,
+                                   I64]),
+    "ictr_icgn_destroy": (None, [VP]),
+    "ictr_icgn_set_stream": (C.c_int, [VP, VP]),
+    "ictr_icgn_set_frames": (C.c_int, [VP, I64, VP, VP]),
+    "ictr_icgn_set_warp": (C.c_int, [VP, I64, DP]),
+    "ictr_icgn_set_timing": (C.c_int, [VP, C.c_int]),
+    "ictr_icgn_run_async": (C.c_int, [VP]),
+    "ictr_icgn_get_results": (C.c_int, [VP, DP, IP, FP]),
+    "ictr_icgn_get_kernel_times": (C.c_int, [VP, FP]),
+    "ictr_icgn_set_rows": (C.c_int, [VP, C.c_int, C.c_int]),
+    "ictr_icgn_enable_sharding": (C.c_int, [VP, C.c_int, VP]),
+    "ictr_icgn_begin": (C.c_int, [VP]),
+    "ictr_icgn_hess_accumulate": (C.c_int, [VP, C.c_int]),
+    "ictr_icgn_hess_finish": (C.c_int, [VP, C.c_int]),
+    "ictr_icgn_iter_accumulate": (C.c_int, [VP, C.c_int]),
+    "ictr_icgn_iter_finish": (C.c_int, [VP, C.c_int]),
 }
 
 _lib = None

@@ -48,6 +48,15 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
+int ictr_fail_(int code, const char *fmt, ...) {  // for the other translation units (ictr_icgn.hip)
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
 #define HIPCHK(expr)                                                                                  \
   do {                                                                                                \
     hipError_t _e = (expr);                                                                           \
@@ -214,6 +223,25 @@ struct ictr_pyramid {
   std::vector<float *> img, dx, dy;  // device planes
   float *arena = nullptr;
 };
+
+struct ictr_pyramid_view {  // internal: what ictr_icgn.hip needs to know about a pyramid
+  int nlev, pad;
+  const int *w, *h, *sw;
+  float *const *img, *const *dx, *const *dy;
+  int getgrad;
+};
+extern "C" int ictr_pyramid_view_(const ictr_pyramid *p, ictr_pyramid_view *v) {
+  v->nlev = p->nlev;
+  v->pad = p->pad;
+  v->w = p->w.data();
+  v->h = p->h.data();
+  v->sw = p->sw.data();
+  v->img = p->img.data();
+  v->dx = p->dx.data();
+  v->dy = p->dy.data();
+  v->getgrad = p->getgrad;
+  return 0;
+}
 
 static void level_size(int w, int h, int level, int *wl, int *hl) {
   auto half = [](int v) {  // cvRound(v*0.5), round-half-even, as cv::resize(dsize=Size(), fx=.5) sizes its output
