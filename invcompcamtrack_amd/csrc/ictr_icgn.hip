@@ -22,6 +22,7 @@
 // composes the warp on the device (same accumulate/tail split as the tracker, ictr_kernels.hip).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -29,6 +30,11 @@
 
 #include "ictr_dev.h"
 #include "se3_math.h"
+
+// Nothing in this file has to round like the reference's CPU build (there is no reference for it): let the compiler
+// contract a*b+c into FMAs here although the library is built with -ffp-contract=off. The kernels are within 2x of
+// being VALU-bound (about 80 lane-instructions per pixel for the homography without FMA), so this matters.
+#pragma clang fp contract(fast)
 
 extern "C" const char *ictr_last_error(void);
 int ictr_fail_(int code, const char *fmt, ...);  // ictr_host.hip
@@ -51,8 +57,7 @@ struct IcState {
   int luinfo[2];
   float b[8];
   float dp[8];
-  float resid;    // mean |r| of the last iteration (diagnostic)
-  int it, active, total_iters, pad_;
+  int it, active, total_iters, pad_[2];
 };
 
 struct IcLevel {
@@ -62,6 +67,7 @@ struct IcLevel {
 
 struct IcDev {
   int B, model, n, nh, maxiter, sharded;
+  int dbg;  // experiments only (ICTR_ICGN_DBG): bit 0 skip the bilinear taps, bit 1 non-temporal tap loads
   int x0, y0, x1, y1;  // template region at level 0 (inclusive-exclusive), scaled per level
   int row_lo, row_hi;  // this rank's rows of the region at level 0 (sharding)
   float eps;
@@ -99,6 +105,12 @@ template <int MODEL> __device__ __forceinline__ void ic_sd(float gx, float gy, f
     sd[7] = gy;
   }
 }
+
+// plane pointers come out of a table in memory, so the compiler cannot prove their address space and would emit
+// flat_load; say "global" explicitly
+typedef const float __attribute__((address_space(1))) *ic_gf32;
+typedef float ic_f4 __attribute__((ext_vector_type(4)));
+typedef const ic_f4 __attribute__((address_space(1))) *ic_gf32x4;
 
 __device__ __forceinline__ float ic_wave_sum(float v) {
 #pragma unroll
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_icgn_hess(IcDev e, IcLevel L, int le
   for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < npx; t += (long)gridDim.x * kBlock) {
     const int y = R.y0 + (int)(t / R.w), x = R.x0 + (int)(t % R.w);
     const size_t o = (size_t)(y + L.pad) * L.sw + x + L.pad;
-    const float gx = pl.dx[o], gy = pl.dy[o];
+    const float gx = ((ic_gf32)pl.dx)[o], gy = ((ic_gf32)pl.dy)[o];
     float sd[N];
     ic_sd<MODEL>(gx, gy, ((float)x - L.cx) * inv_f, ((float)y - L.cy) * inv_f, sd);
     int jk = 0;
@@ -159,53 +171,93 @@ __global__ __launch_bounds__(kBlock) void k_icgn_hess(IcDev e, IcLevel L, int le
         (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
 }
 
-// b = sum sd^T (I(W(x)) - T(x)) for the current warp
+// b = sum sd^T (I(W(x)) - T(x)) for the current warp.
+// V = 4: a lane owns four consecutive pixels of a row, read as one aligned 16-byte load per plane (a wave streams
+// 1 KB per plane per step); rows are cut into quads aligned to the padded plane, pixels of a quad outside the region
+// are masked. V = 1: scalar form for planes whose stride is not a multiple of four floats.
 template <int MODEL>
+__device__ __forceinline__ void ic_pixel(ic_gf32 cur, const IcLevel &L, const float *M, float inv_f,
+                                         float xmax, float ymax, int x, float ny, float tv, float gx, float gy,
+                                         float *acc, int dbg) {
+  constexpr int N = model_np(MODEL);
+  const float nx = ((float)x - L.cx) * inv_f;
+  const float u = M[0] * nx + M[1] * ny + M[2];
+  const float v = M[3] * nx + M[4] * ny + M[5];
+  float iw = 1.0f;
+  if constexpr (MODEL == kHomog) iw = 1.0f / (M[6] * nx + M[7] * ny + M[8]);
+  const float px = u * iw * L.f + L.cx, py = v * iw * L.f + L.cy;
+  if ((px >= 0.0f) & (py >= 0.0f) & (px <= xmax) & (py <= ymax)) {  // NaN-safe; outside pixels contribute nothing
+    const float fxf = floorf(px), fyf = floorf(py);
+    const float ax = px - fxf, ay = py - fyf;
+    ic_gf32 q = cur + ((size_t)((int)fyf + L.pad) * L.sw + (int)fxf + L.pad);
+    float i00, i01, i10, i11;
+    if (dbg & 1) {
+      i00 = i01 = i10 = i11 = tv + ax;
+    } else if (dbg & 2) {
+      i00 = __builtin_nontemporal_load(q), i01 = __builtin_nontemporal_load(q + 1);
+      i10 = __builtin_nontemporal_load(q + L.sw), i11 = __builtin_nontemporal_load(q + L.sw + 1);
+    } else {
+      i00 = q[0], i01 = q[1], i10 = q[L.sw], i11 = q[L.sw + 1];
+    }
+    const float iv = (i00 * (1.0f - ax) + i01 * ax) * (1.0f - ay) + (i10 * (1.0f - ax) + i11 * ax) * ay;
+    const float r = iv - tv;
+    float sd[N];
+    ic_sd<MODEL>(gx, gy, nx, ny, sd);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] += sd[k] * r;
+  }
+}
+
+template <int MODEL, int V>
 __global__ __launch_bounds__(kBlock) void k_icgn_iter(IcDev e, IcLevel L, int level) {
   constexpr int N = model_np(MODEL);
-  __shared__ float sW[kWaves][kIcPartB + 1];
+  __shared__ float sW[kWaves][kIcPartB];
   const int b = blockIdx.y;
   const IcState &st = e.st[b];
   if (!st.active) return;
   const PlaneSet pl = e.planes[b * e.nlev + level];
-  const float *__restrict__ T = pl.ref;
-  const float *__restrict__ Gx = pl.dx;
-  const float *__restrict__ Gy = pl.dy;
-  const float *__restrict__ cur = pl.cur;
+  const ic_gf32 T = (ic_gf32)pl.ref, Gx = (ic_gf32)pl.dx, Gy = (ic_gf32)pl.dy, cur = (ic_gf32)pl.cur;
   const IcRegion R = ic_region(e, level);
-  const long npx = (long)R.w * R.h;
   float M[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) M[k] = st.M[k];
+  for (int k = 0; k < 9; ++k) M[k] = st.M[k];  // affine models keep the last row at (0,0,1): M is normalised by M[8]
   float acc[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) acc[k] = 0.0f;
-  float rabs = 0.0f;
   const float inv_f = 1.0f / L.f;
   const float xmax = (float)(L.w - 1), ymax = (float)(L.h - 1);
-  for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < npx; t += (long)gridDim.x * kBlock) {
-    const int y = R.y0 + (int)(t / R.w), x = R.x0 + (int)(t % R.w);
-    const size_t o = (size_t)(y + L.pad) * L.sw + x + L.pad;
-    const float tv = __builtin_nontemporal_load(T + o), gx = __builtin_nontemporal_load(Gx + o),
-                gy = __builtin_nontemporal_load(Gy + o);
-    const float nx = ((float)x - L.cx) * inv_f, ny = ((float)y - L.cy) * inv_f;
-    const float u = M[0] * nx + M[1] * ny + M[2];
-    const float v = M[3] * nx + M[4] * ny + M[5];
-    const float wq = M[6] * nx + M[7] * ny + M[8];
-    const float iw = 1.0f / wq;
-    const float px = u * iw * L.f + L.cx, py = v * iw * L.f + L.cy;
-    if ((px >= 0.0f) & (py >= 0.0f) & (px <= xmax) & (py <= ymax)) {  // NaN-safe; outside pixels contribute nothing
-      const float fxf = floorf(px), fyf = floorf(py);
-      const float ax = px - fxf, ay = py - fyf;
-      const size_t q = (size_t)((int)fyf + L.pad) * L.sw + (int)fxf + L.pad;
-      const float i00 = cur[q], i01 = cur[q + 1], i10 = cur[q + L.sw], i11 = cur[q + L.sw + 1];
-      const float iv = (i00 * (1.0f - ax) + i01 * ax) * (1.0f - ay) + (i10 * (1.0f - ax) + i11 * ax) * ay;
-      const float r = iv - tv;
-      float sd[N];
-      ic_sd<MODEL>(gx, gy, nx, ny, sd);
+  if constexpr (V == 4) {
+    // a workgroup owns a tile of 256 pixels x 4 rows (wave w = row w, lane = quad): the four waves' bilinear taps
+    // overlap in 3 of their 5 rows, which the CU's L1 serves
+    const int xs = R.x0 - ((R.x0 + L.pad) & 3);       // first quad starts on a 16-byte boundary of the padded row
+    const int nq = (R.x0 + R.w - xs + 3) >> 2;
+    const int ntx = (nq + 63) >> 6, nty = (R.h + kWaves - 1) / kWaves;
+    const int xe = R.x0 + R.w;
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    typedef ic_f4 f4;
+    for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
+      const int ty = t / ntx, tx = t - ty * ntx;
+      const int row = ty * kWaves + wave_, q = tx * 64 + lane_;
+      if ((row >= R.h) | (q >= nq)) continue;
+      const int y = R.y0 + row, x = xs + 4 * q;
+      const size_t o = (size_t)(y + L.pad) * L.sw + (x + L.pad);
+      const f4 tv = __builtin_nontemporal_load((ic_gf32x4)(T + o));
+      const f4 gx = __builtin_nontemporal_load((ic_gf32x4)(Gx + o));
+      const f4 gy = __builtin_nontemporal_load((ic_gf32x4)(Gy + o));
+      const float ny = ((float)y - L.cy) * inv_f;
 #pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] += sd[k] * r;
-      rabs += fabsf(r);
+      for (int j = 0; j < 4; ++j)
+        if ((x + j >= R.x0) & (x + j < xe))
+          ic_pixel<MODEL>(cur, L, M, inv_f, xmax, ymax, x + j, ny, tv[j], gx[j], gy[j], acc, e.dbg);
+    }
+  } else {
+    const long npx = (long)R.w * R.h;
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < npx; t += (long)gridDim.x * kBlock) {
+      const int y = R.y0 + (int)(t / R.w), x = R.x0 + (int)(t % R.w);
+      const size_t o = (size_t)(y + L.pad) * L.sw + x + L.pad;
+      const float tv = __builtin_nontemporal_load(T + o), gx = __builtin_nontemporal_load(Gx + o),
+                  gy = __builtin_nontemporal_load(Gy + o);
+      ic_pixel<MODEL>(cur, L, M, inv_f, xmax, ymax, x, ((float)y - L.cy) * inv_f, tv, gx, gy, acc, e.dbg);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -213,10 +265,6 @@ __global__ __launch_bounds__(kBlock) void k_icgn_iter(IcDev e, IcLevel L, int le
   for (int k = 0; k < N; ++k) {
     const float v = ic_wave_sum(acc[k]);
     if (lane == 0) sW[wave][k] = v;
-  }
-  {
-    const float v = ic_wave_sum(rabs);
-    if (lane == 0) sW[wave][kIcPartB] = v;
   }
   __syncthreads();
   if (threadIdx.x < N)
@@ -441,6 +489,8 @@ struct ictr_icgn {
   int rows[2] = {0, 0};
   int sharded = 0;
   int gridx = 1;
+  int dbg = 0;
+  bool scalar_only = false;  // ICTR_ICGN_SCALAR=1: force the one-pixel-per-lane kernels (A/B measurements)
   hipStream_t stream = nullptr;
   IcState *d_st = nullptr;
   PlaneSet *d_planes = nullptr;
@@ -469,6 +519,7 @@ static IcDev icgn_dev(const ictr_icgn *g) {
   e.nh = e.n * (e.n + 1) / 2;
   e.maxiter = g->maxiter;
   e.sharded = g->sharded;
+  e.dbg = g->dbg;
   e.x0 = g->region[0];
   e.y0 = g->region[1];
   e.x1 = g->region[0] + g->region[2];
@@ -530,9 +581,15 @@ extern "C" int ictr_icgn_create(ictr_icgn **out, int model, int w, int h, int lv
   }
   g->rows[0] = 0;
   g->rows[1] = h;
+  if (const char *sv = getenv("ICTR_ICGN_SCALAR")) g->scalar_only = atoi(sv) != 0;
+  if (const char *sv = getenv("ICTR_ICGN_DBG")) g->dbg = atoi(sv);
   const long npx = (long)g->region[2] * g->region[3];
-  g->gridx = (int)std::min<long>(std::max<long>((npx + kBlock - 1) / kBlock, 1),
-                                 std::max<long>(64, 2 * kMaxGridX / g->B));
+  // workgroups per problem: enough to fill the chip a few times over, few enough that the tails' reductions and the
+  // idle-block prologues stay cheap on the small levels (measured: 8 K total is the best level-0 choice, 32 K costs
+  // 5 % there and 4x on the coarse levels); smaller levels launch fewer (icgn_grid)
+  long want = std::max<long>(64, 8192 / g->B);
+  if (const char *sv = getenv("ICTR_ICGN_GRIDX")) want = atol(sv);
+  g->gridx = (int)std::max<long>(want, 1);
   hipError_t e = hipSuccess;
   auto alloc = [&](void **p, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(p, bytes);
@@ -600,6 +657,8 @@ extern "C" int ictr_icgn_set_warp(ictr_icgn *g, int64_t problem, const double *M
   if (!g || problem < 0 || problem >= g->B) return ictr_fail_(ICTR_ERR_INVALID, "icgn_set_warp: bad arguments");
   double K[9], Ki[9], t[9], Mn[9];
   const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (M9 && g->model != kHomog && (M9[6] != 0.0 || M9[7] != 0.0 || M9[8] == 0.0))
+    return ictr_fail_(ICTR_ERR_INVALID, "icgn_set_warp: a projective initial warp needs the homography model");
   icgn_K(g, K, Ki);
   m3_mul(Ki, M9 ? M9 : I, t);
   m3_mul(t, K, Mn);
@@ -642,6 +701,16 @@ extern "C" int ictr_icgn_begin(ictr_icgn *g) {
   return ICTR_OK;
 }
 
+// workgroups per problem at one level: at most gridx, at most one per work unit, and balanced (every workgroup gets
+// the same number of units, +-1)
+static int icgn_grid(const ictr_icgn *g, int level, bool vec) {
+  const int s = 1 << level;
+  const long w = std::max(g->region[2] / s, 1), h = std::max(g->region[3] / s + 1, 1);
+  const long units = vec ? ((w + 255) / 256 + 1) * ((h + 3) / 4) : (w * h + kBlock - 1) / kBlock;
+  const long per = (units + g->gridx - 1) / g->gridx;
+  return (int)std::max<long>(1, std::min<long>(g->gridx, (units + per - 1) / per));
+}
+
 template <typename F> static void icgn_dispatch(int model, F &&f) {
   switch (model) {
     case kTrans: f(std::integral_constant<int, kTrans>()); break;
@@ -655,28 +724,37 @@ extern "C" int ictr_icgn_hess_accumulate(ictr_icgn *g, int level) {
   if (!g || level < g->lv_l || level > g->lv_f) return ictr_fail_(ICTR_ERR_INVALID, "icgn: bad level");
   const IcDev e = icgn_dev(g);
   const IcLevel L = icgn_level(g, level);
-  const dim3 grid(g->gridx, g->B), blk(kBlock);
+  const int nblk = icgn_grid(g, level, false);
+  const dim3 grid(nblk, g->B), blk(kBlock);
   icgn_dispatch(g->model, [&](auto m) { hipLaunchKernelGGL((k_icgn_hess<decltype(m)::value>), grid, blk, 0, g->stream, e, L, level); });
-  hipLaunchKernelGGL(k_icgn_hess_tail, dim3(g->B), blk, 0, g->stream, e, g->gridx, 0);
+  hipLaunchKernelGGL(k_icgn_hess_tail, dim3(g->B), blk, 0, g->stream, e, nblk, 0);
   HIPCHK_IC(hipGetLastError());
   return ICTR_OK;
 }
 extern "C" int ictr_icgn_hess_finish(ictr_icgn *g, int level) {
   if (!g) return ictr_fail_(ICTR_ERR_INVALID, "icgn is NULL");
-  if (g->sharded) hipLaunchKernelGGL(k_icgn_hess_tail, dim3(g->B), dim3(kBlock), 0, g->stream, icgn_dev(g), g->gridx, 1);
+  if (g->sharded) hipLaunchKernelGGL(k_icgn_hess_tail, dim3(g->B), dim3(kBlock), 0, g->stream, icgn_dev(g), 0, 1);
   HIPCHK_IC(hipGetLastError());
   return ICTR_OK;
 }
-static void icgn_iter_main(ictr_icgn *g, const IcDev &e, const IcLevel &L, int level) {
-  const dim3 grid(g->gridx, g->B), blk(kBlock);
-  icgn_dispatch(g->model, [&](auto m) { hipLaunchKernelGGL((k_icgn_iter<decltype(m)::value>), grid, blk, 0, g->stream, e, L, level); });
+static int icgn_iter_main(ictr_icgn *g, const IcDev &e, const IcLevel &L, int level) {  // returns workgroups per problem
+  const bool vec = g->pad >= 4 && (L.sw & 3) == 0 && !g->scalar_only;
+  const int nblk = icgn_grid(g, level, vec);
+  const dim3 grid(nblk, g->B), blk(kBlock);
+  icgn_dispatch(g->model, [&](auto m) {
+    if (vec)
+      hipLaunchKernelGGL((k_icgn_iter<decltype(m)::value, 4>), grid, blk, 0, g->stream, e, L, level);
+    else
+      hipLaunchKernelGGL((k_icgn_iter<decltype(m)::value, 1>), grid, blk, 0, g->stream, e, L, level);
+  });
+  return nblk;
 }
 extern "C" int ictr_icgn_iter_accumulate(ictr_icgn *g, int level) {
   if (!g || level < g->lv_l || level > g->lv_f) return ictr_fail_(ICTR_ERR_INVALID, "icgn: bad level");
   const IcDev e = icgn_dev(g);
   const IcLevel L = icgn_level(g, level);
-  icgn_iter_main(g, e, L, level);
-  hipLaunchKernelGGL(k_icgn_iter_tail, dim3(g->B), dim3(kBlock), 0, g->stream, e, L.f, g->gridx, 0);
+  const int nblk = icgn_iter_main(g, e, L, level);
+  hipLaunchKernelGGL(k_icgn_iter_tail, dim3(g->B), dim3(kBlock), 0, g->stream, e, L.f, nblk, 0);
   HIPCHK_IC(hipGetLastError());
   return ICTR_OK;
 }
@@ -684,7 +762,7 @@ extern "C" int ictr_icgn_iter_finish(ictr_icgn *g, int level) {
   if (!g) return ictr_fail_(ICTR_ERR_INVALID, "icgn is NULL");
   if (g->sharded) {
     const IcLevel L = icgn_level(g, level);
-    hipLaunchKernelGGL(k_icgn_iter_tail, dim3(g->B), dim3(kBlock), 0, g->stream, icgn_dev(g), L.f, g->gridx, 1);
+    hipLaunchKernelGGL(k_icgn_iter_tail, dim3(g->B), dim3(kBlock), 0, g->stream, icgn_dev(g), L.f, 0, 1);
   }
   HIPCHK_IC(hipGetLastError());
   return ICTR_OK;
@@ -701,16 +779,16 @@ extern "C" int ictr_icgn_run_async(ictr_icgn *g) {
     for (int it = 0; it < g->maxiter; ++it) {
       const bool tk = g->timing && !g->ev.empty();
       if (tk) HIPCHK_IC(hipEventRecord(g->ev[2 * ((size_t)l * g->maxiter + it)], g->stream));
-      icgn_iter_main(g, e, L, l);
+      const int nblk = icgn_iter_main(g, e, L, l);
       if (tk) HIPCHK_IC(hipEventRecord(g->ev[2 * ((size_t)l * g->maxiter + it) + 1], g->stream));
-      hipLaunchKernelGGL(k_icgn_iter_tail, dim3(g->B), dim3(kBlock), 0, g->stream, e, L.f, g->gridx, 0);
+      hipLaunchKernelGGL(k_icgn_iter_tail, dim3(g->B), dim3(kBlock), 0, g->stream, e, L.f, nblk, 0);
     }
   }
   HIPCHK_IC(hipGetLastError());
   return ICTR_OK;
 }
 
-// results: warps (row-major 3x3, level-0 pixel coordinates), iterations, last mean |residual|
+// results: warps (row-major 3x3, level-0 pixel coordinates), iterations, last dp
 extern "C" int ictr_icgn_get_results(ictr_icgn *g, double *M9_out, int *iters, float *last_dp) {
   if (!g) return ictr_fail_(ICTR_ERR_INVALID, "icgn is NULL");
   HIPCHK_IC(hipMemcpyAsync(g->h_st.data(), g->d_st, sizeof(IcState) * g->B, hipMemcpyDeviceToHost, g->stream));

@@ -15,6 +15,8 @@ CONFIGS = {
     "C3-1080p-affine": dict(w=1920, h=1080, model="affine", p=[0.003, -0.002, 0.004, -0.003, 3.1, -2.2], lv_f=2, B=8),
     "C5-4k-homography": dict(w=3840, h=2160, model="homography",
                              p=[0.002, -0.001, 2e-6, 0.002, -0.002, -3e-6, 3.1, -2.2], lv_f=3, B=4),
+    "X-4k-translation": dict(w=3840, h=2160, model="translation", p=[3.1, -2.2], lv_f=3, B=4),
+    "X-4k-affine": dict(w=3840, h=2160, model="affine", p=[0.002, -0.001, 0.002, -0.002, 3.1, -2.2], lv_f=3, B=4),
 }
 
 
