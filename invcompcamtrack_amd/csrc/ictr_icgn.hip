@@ -229,7 +229,10 @@ __global__ __launch_bounds__(kBlock) void k_icgn_iter(IcDev e, IcLevel L, int le
   if constexpr (V == 4) {
     // a workgroup owns a tile of 256 pixels x 4 rows (wave w = row w, lane = quad): the four waves' bilinear taps
     // overlap in 3 of their 5 rows, which the CU's L1 serves
-    const int xs = R.x0 - ((R.x0 + L.pad) & 3);       // first quad starts on a 16-byte boundary of the padded row
+    // first quad on a 16-byte boundary of the padded row; when the row pitch is a multiple of 128 bytes (e.g. width
+    // % 32 == 0 and padding 16) on a cache-line boundary, so that no line is shared between two tiles (measured with
+    // padding 4: 19 % HBM over-fetch, every 1-KB tile row touching 9 lines instead of 8)
+    const int xs = R.x0 - ((R.x0 + L.pad) & ((L.sw & 31) == 0 ? 31 : 3));
     const int nq = (R.x0 + R.w - xs + 3) >> 2;
     const int ntx = (nq + 63) >> 6, nty = (R.h + kWaves - 1) / kWaves;
     const int xe = R.x0 + R.w;
@@ -261,6 +264,140 @@ __global__ __launch_bounds__(kBlock) void k_icgn_iter(IcDev e, IcLevel L, int le
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float v = ic_wave_sum(acc[k]);
+    if (lane == 0) sW[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < N)
+    e.partb[((size_t)b * gridDim.x + blockIdx.x) * kIcPartB + threadIdx.x] =
+        (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+}
+
+// LDS-staged form of k_icgn_iter: the gathered bilinear taps were the inefficient stream of the direct form (25 % of
+// the bytes, 33 % of the time; profiles/r01_icgn.md), so the workgroup first copies the bounding box of its tile's
+// warped footprint into LDS with the same aligned 16-byte row loads the template planes get, then every pixel takes
+// its four taps from LDS. Tile = 256 pixels x 4 rows (wave = row, lane + 64 j = pixel: adjacent lanes read adjacent
+// LDS words, no bank conflicts). A projective warp maps the convex tile into the convex hull of its warped corners, so
+// the corners bound the footprint; one pixel of slack absorbs rounding. Tiles whose footprint does not fit the LDS
+// window (strong rotation / scale) fall back to direct gathers, so the result never depends on the window size.
+constexpr int kIcLW = 288, kIcLH = 12;  // LDS window: 288 x 12 floats = 13.5 KB per workgroup
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_icgn_iter_lds(IcDev e, IcLevel L, int level) {
+  constexpr int N = model_np(MODEL);
+  __shared__ __attribute__((aligned(16))) float sTile[kIcLH * kIcLW];
+  __shared__ float sW[kWaves][kIcPartB];
+  const int b = blockIdx.y;
+  const IcState &st = e.st[b];
+  if (!st.active) return;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const ic_gf32 T = (ic_gf32)pl.ref, Gx = (ic_gf32)pl.dx, Gy = (ic_gf32)pl.dy, cur = (ic_gf32)pl.cur;
+  const IcRegion R = ic_region(e, level);
+  float M[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) M[k] = st.M[k];
+  float acc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = 0.0f;
+  const float inv_f = 1.0f / L.f;
+  const float xmax = (float)(L.w - 1), ymax = (float)(L.h - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntx = (R.w + 255) >> 8, nty = (R.h + kWaves - 1) / kWaves;
+  const int xe = R.x0 + R.w;
+
+  auto warp_pt = [&](float x, float y, float &px, float &py) -> bool {
+    const float nx = (x - L.cx) * inv_f, ny = (y - L.cy) * inv_f;
+    const float u = M[0] * nx + M[1] * ny + M[2], v = M[3] * nx + M[4] * ny + M[5];
+    float wq = 1.0f;
+    if constexpr (MODEL == kHomog) wq = M[6] * nx + M[7] * ny + M[8];
+    const float iw = 1.0f / wq;
+    px = u * iw * L.f + L.cx;
+    py = v * iw * L.f + L.cy;
+    return wq > 1e-6f;
+  };
+
+  for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
+    const int ty = t / ntx, tx = t - ty * ntx;
+    const int tx0 = R.x0 + (tx << 8), ty0 = R.y0 + ty * kWaves;
+    const int txl = min(tx0 + 255, xe - 1), tyl = min(ty0 + kWaves - 1, R.y0 + R.h - 1);
+    // ---- footprint of the tile in the current frame (wave-uniform arithmetic)
+    float cxs[4], cys[4];
+    bool okc = warp_pt((float)tx0, (float)ty0, cxs[0], cys[0]);
+    okc &= warp_pt((float)txl, (float)ty0, cxs[1], cys[1]);
+    okc &= warp_pt((float)tx0, (float)tyl, cxs[2], cys[2]);
+    okc &= warp_pt((float)txl, (float)tyl, cxs[3], cys[3]);
+    const float fxmin = fminf(fminf(cxs[0], cxs[1]), fminf(cxs[2], cxs[3]));
+    const float fxmax = fmaxf(fmaxf(cxs[0], cxs[1]), fmaxf(cxs[2], cxs[3]));
+    const float fymin = fminf(fminf(cys[0], cys[1]), fminf(cys[2], cys[3]));
+    const float fymax = fmaxf(fmaxf(cys[0], cys[1]), fmaxf(cys[2], cys[3]));
+    okc &= (fxmax - fxmin < 4096.0f) & (fymax - fymin < 4096.0f) & (fabsf(fxmin) < 1e6f) & (fabsf(fymin) < 1e6f);
+    int bx0 = 0, by0 = 0, ncols = 0, nrows = 0;
+    if (okc) {
+      const int cx0 = max((int)floorf(fxmin) - 1, -L.pad), cx1 = min((int)floorf(fxmax) + 2, L.w - 1 + L.pad);
+      const int cy0 = max((int)floorf(fymin) - 1, -L.pad), cy1 = min((int)floorf(fymax) + 2, L.h - 1 + L.pad);
+      bx0 = cx0 - ((cx0 + L.pad) & 3);  // 16-byte aligned start inside the padded row
+      by0 = cy0;
+      ncols = cx1 - bx0 + 1;
+      nrows = cy1 - cy0 + 1;
+    }
+    const bool staged = okc & (ncols > 0) & (nrows > 0) & (ncols <= kIcLW) & (nrows <= kIcLH);
+    // ---- this lane's template pixels: row ty0 + wave, columns tx0 + lane + 64 j (issued before the LDS fill)
+    const int y = ty0 + wave;
+    const bool rowok = y <= tyl;
+    float tv[4], gxv[4], gyv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = tx0 + lane + 64 * j;
+      tv[j] = gxv[j] = gyv[j] = 0.0f;
+      if (rowok & (x < xe)) {
+        const size_t o = (size_t)(y + L.pad) * L.sw + (x + L.pad);
+        tv[j] = __builtin_nontemporal_load(T + o);
+        gxv[j] = __builtin_nontemporal_load(Gx + o);
+        gyv[j] = __builtin_nontemporal_load(Gy + o);
+      }
+    }
+    if (staged) {
+      const int n4 = (ncols + 3) >> 2;
+      for (int r = wave; r < nrows; r += kWaves) {
+        const ic_gf32 src = cur + ((size_t)(by0 + r + L.pad) * L.sw + (bx0 + L.pad));
+        for (int c4 = lane; c4 < n4; c4 += 64)
+          *reinterpret_cast<ic_f4 *>(&sTile[r * kIcLW + 4 * c4]) = *(ic_gf32x4)(src + 4 * c4);
+      }
+    }
+    __syncthreads();
+    const float ny = ((float)y - L.cy) * inv_f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = tx0 + lane + 64 * j;
+      if (!(rowok & (x < xe))) continue;
+      if (!staged) {
+        ic_pixel<MODEL>(cur, L, M, inv_f, xmax, ymax, x, ny, tv[j], gxv[j], gyv[j], acc, 0);
+        continue;
+      }
+      const float nx = ((float)x - L.cx) * inv_f;
+      const float u = M[0] * nx + M[1] * ny + M[2];
+      const float v = M[3] * nx + M[4] * ny + M[5];
+      float iw = 1.0f;
+      if constexpr (MODEL == kHomog) iw = 1.0f / (M[6] * nx + M[7] * ny + M[8]);
+      const float px = u * iw * L.f + L.cx, py = v * iw * L.f + L.cy;
+      if ((px >= 0.0f) & (py >= 0.0f) & (px <= xmax) & (py <= ymax)) {
+        const float fxf = floorf(px), fyf = floorf(py);
+        const float ax = px - fxf, ay = py - fyf;
+        int q = ((int)fyf - by0) * kIcLW + ((int)fxf - bx0);
+        q = min(max(q, 0), (kIcLH - 1) * kIcLW - 2);  // never outside the window, whatever the rounding did
+        const float i00 = sTile[q], i01 = sTile[q + 1], i10 = sTile[q + kIcLW], i11 = sTile[q + kIcLW + 1];
+        const float iv = (i00 * (1.0f - ax) + i01 * ax) * (1.0f - ay) + (i10 * (1.0f - ax) + i11 * ax) * ay;
+        const float r = iv - tv[j];
+        float sd[N];
+        ic_sd<MODEL>(gxv[j], gyv[j], nx, ny, sd);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += sd[k] * r;
+      }
+    }
+    __syncthreads();  // the window is refilled by the next tile
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const float v = ic_wave_sum(acc[k]);
@@ -490,6 +627,7 @@ struct ictr_icgn {
   int sharded = 0;
   int gridx = 1;
   int dbg = 0;
+  bool lds = false;          // ICTR_ICGN_LDS=1: LDS-staged footprint instead of direct tap gathers (measured: no gain)
   bool scalar_only = false;  // ICTR_ICGN_SCALAR=1: force the one-pixel-per-lane kernels (A/B measurements)
   hipStream_t stream = nullptr;
   IcState *d_st = nullptr;
@@ -583,6 +721,7 @@ extern "C" int ictr_icgn_create(ictr_icgn **out, int model, int w, int h, int lv
   g->rows[1] = h;
   if (const char *sv = getenv("ICTR_ICGN_SCALAR")) g->scalar_only = atoi(sv) != 0;
   if (const char *sv = getenv("ICTR_ICGN_DBG")) g->dbg = atoi(sv);
+  if (const char *sv = getenv("ICTR_ICGN_LDS")) g->lds = atoi(sv) != 0;
   const long npx = (long)g->region[2] * g->region[3];
   // workgroups per problem: enough to fill the chip a few times over, few enough that the tails' reductions and the
   // idle-block prologues stay cheap on the small levels (measured: 8 K total is the best level-0 choice, 32 K costs
@@ -742,7 +881,9 @@ static int icgn_iter_main(ictr_icgn *g, const IcDev &e, const IcLevel &L, int le
   const int nblk = icgn_grid(g, level, vec);
   const dim3 grid(nblk, g->B), blk(kBlock);
   icgn_dispatch(g->model, [&](auto m) {
-    if (vec)
+    if (vec && g->lds)
+      hipLaunchKernelGGL((k_icgn_iter_lds<decltype(m)::value>), grid, blk, 0, g->stream, e, L, level);
+    else if (vec)
       hipLaunchKernelGGL((k_icgn_iter<decltype(m)::value, 4>), grid, blk, 0, g->stream, e, L, level);
     else
       hipLaunchKernelGGL((k_icgn_iter<decltype(m)::value, 1>), grid, blk, 0, g->stream, e, L, level);

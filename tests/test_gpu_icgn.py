@@ -148,3 +148,35 @@ def test_errors():
         e.set_frames(0, ic.Pyramid(a, 1, 1), ic.Pyramid(a, 1, 1))              # padding < 2
     with pytest.raises(ic.IctrError):
         e.set_frames(0, ic.Pyramid(a, 0, 4), ic.Pyramid(a, 0, 4))              # too few levels
+
+
+@pytest.mark.parametrize("model,p", [("se2", [0.08, 3.0, -2.0]),
+                                      ("affine", [0.08, -0.05, 0.06, -0.07, 2.0, 1.0]),
+                                      ("homography", [0.01, -0.02, 4e-5, 0.03, 0.01, -5e-5, 1.5, -1.0])])
+def test_lds_staged_kernel_equals_direct_gathers(oracle, monkeypatch, model, p):
+    """Strong warps: some tiles' footprints do not fit the LDS window and take the direct-gather fallback; the
+    LDS-staged kernel, the direct kernel and the scalar kernel agree with each other and with the oracle."""
+    from oracle import np_icgn as NI
+    w, h, lv_f, pad = 640, 480, 2, 4
+    C = np.array([[1, 0, w / 2], [0, 1, h / 2], [0, 0, 1.0]])
+    Mgt = C @ icgn.warp_matrix(model, p) @ np.linalg.inv(C)
+    Mgt /= Mgt[2, 2]
+    a, b = icgn.make_warped_pair(w, h, Mgt)
+    ga, gb = ic.Pyramid(a, lv_f, pad), ic.Pyramid(b, lv_f, pad, getgrad=False)
+    res = {}
+    for name, env in [("lds", {"ICTR_ICGN_LDS": "1"}), ("direct", {}), ("scalar", {"ICTR_ICGN_SCALAR": "1"})]:
+        for k in ("ICTR_ICGN_LDS", "ICTR_ICGN_SCALAR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = icgn.AlignBatch(model, w, h, lv_f, 0, 6, 0.0, None, 1)
+        eng.set_frames(0, ga, gb)
+        eng.run_async()
+        res[name] = eng.results()[0][0]
+    _, pa, _ = planes(oracle, a, lv_f, pad)
+    _, _, pb = planes(oracle, b, lv_f, pad)
+    Mo, _ = NI.align(pa, pb, pad, w, h, icgn.MODELS[model], lv_f, maxiter=6)
+    for name in res:
+        assert corner_err(res[name], Mo, w, h) < 5e-3, name
+    assert corner_err(res["lds"], res["direct"], w, h) < 2e-3
+    assert corner_err(res["lds"], Mgt, w, h) < 0.05

@@ -20,7 +20,7 @@ CONFIGS = {
 }
 
 
-def main(names, steps=5, maxiter=10):
+def main(names, steps=5, maxiter=10, pad=int(__import__('os').environ.get('ICGN_PAD', '16'))):
     for name in names:
         c = CONFIGS[name]
         w, h, lv_f, B = c["w"], c["h"], c["lv_f"], c["B"]
@@ -30,7 +30,7 @@ def main(names, steps=5, maxiter=10):
         keep = []
         for k in range(B):
             a, b = icgn.make_warped_pair(w, h, Mgt, seed=100 + k)
-            pa, pb = ic.Pyramid(a, lv_f, 4), ic.Pyramid(b, lv_f, 4, getgrad=False)
+            pa, pb = ic.Pyramid(a, lv_f, pad), ic.Pyramid(b, lv_f, pad, getgrad=False)
             eng.set_frames(k, pa, pb)
             keep.append((pa, pb))
         eng.set_timing(True)
@@ -49,7 +49,7 @@ def main(names, steps=5, maxiter=10):
         kt = eng.kernel_times()
         npx = [((w - 4) >> l) * ((h - 4) >> l) for l in range(lv_f + 1)]
         px_iters = B * sum(npx) * maxiter
-        out = dict(config=name, B=B, maxiter=maxiter, ms_per_step=dt * 1e3, gpix_iter_per_s=px_iters / dt / 1e9,
+        out = dict(config=name, pad=pad, B=B, maxiter=maxiter, ms_per_step=dt * 1e3, gpix_iter_per_s=px_iters / dt / 1e9,
                    corner_err_px_max=max(errs), iters=int(it[0]),
                    level_kernel_us=[float(kt[l]) * 1e3 / maxiter for l in range(lv_f + 1)],
                    level_gbps=[16.0 * B * npx[l] / (float(kt[l]) * 1e-3 / maxiter) / 1e9 if kt[l] > 0 else None
