@@ -7,15 +7,17 @@ Workload "R1080p-dense-se3" (default): the reference-faithful tracker (OdometerC
 an 8-px grid that tiles the frame exactly (240 x 135 = 32 400 points => 2 073 600 aligned pixels per GN
 iteration, the pixel count of a full 1080p frame), maxiter=10 with normdp_ratio=0 (fixed iteration count, so
 every launch does full work), donorm=0, dopatchnorm=0. A "step" is one coarse-to-fine tracking (SetPose
-projection + 3 levels x [setup + 10 GN iterations]) of a batch of B independent frame pairs (default 16: each
-pair has its own pyramids and patch buffers, so one GN iteration streams B x 33 MB and cannot live in the 256 MB
-Infinity Cache). Inputs (pyramids, 3-D points) are resident in HBM before the timed region; the timed region
-ends with the poses on the host.
+projection + 3 levels x [setup + 10 GN iterations]) of a batch of B independent frame pairs (default 32: each
+pair has its own pyramids and patch buffers, so one GN iteration streams B x 33 MB = 1.06 GB, far beyond the 256 MB
+Infinity Cache; measured: 16 pairs 238, 32 pairs 266, 64 pairs 270 Gpix/s -- fixed launch/tail costs amortise).
+Inputs (pyramids, 3-D points) are resident in HBM before the timed region; every step ends with its poses on the
+host. In single-GPU mode two engines take the steps in turn on one stream so that the host prepares step i+1 while
+the GPU runs step i (kernels never overlap; --no-pipeline restores strict alternation).
 
   value        = aligned pixels / s  (pixels entering the residual, all levels, all problems, all ranks) in Mpix/s
-  roofline     = the level-0 GN-iteration kernel: algorithmic bytes (16 B per patch pixel: T, Gx, Gy, one
-                 current-frame texel) per launch / mean launch duration, measured with HIP events
-                 on the kernel's stream over the timed steps, vs 8 TB/s HBM3E.
+  roofline     = the GN-iteration kernel k_iter8: algorithmic bytes (16 B per patch pixel: T, Gx, Gy, one
+                 current-frame texel) per launch / mean duration of all its launches, measured
+                 with HIP events on the kernel's stream over the timed steps, vs 8 TB/s HBM3E.
   cpu_baseline = the oracle (C restatement of the reference, one thread, -O3 -msse4 -mavx) timed on the same
                  workload for one frame pair (a bounded sample), on this host's cores.
 
@@ -42,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="independent frame pairs per step (per rank)")
+    ap.add_argument("--batch", type=int, default=32, help="independent frame pairs per step (per rank)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--levels", type=int, default=3)
@@ -51,6 +53,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (bit0: LDS-staged current-frame window)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one engine, host and GPU strictly alternate (the pre-pipelining behaviour)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on ONE GPU: all ranks use cuda:0 and the 27*B floats are all-reduced through "
                          "host memory with gloo (same kernels, same phase sequence; numbers are not a benchmark)")
@@ -72,7 +76,11 @@ def build_inputs(args, rank, world):
     n_pts = scenes[0]["pts3d"].shape[1]
     op = ic.optparam(lv_f, 0, P, args.maxiter, 0.0, 0, 0, n_pts)
     cam = ic.CamClass(lv_f + 1, scenes[0]["fc"], scenes[0]["cc"], scenes[0]["wh"], P)
-    batch = ic.TrackBatch(cam, op, args.batch)
+    # Two engines take the steps in turn on one stream (single-GPU mode): while the GPU runs step i on one, the host
+    # prepares and enqueues step i+1 on the other, then collects step i's poses (each engine waits for its own
+    # end-of-tracking event only). Kernels never overlap; the GPU just does not idle during the host's SetPose work.
+    n_eng = 1 if (world > 1 or args.no_pipeline) else 2
+    engines = [ic.TrackBatch(cam, op, args.batch) for _ in range(n_eng)]
     pyrs = []
     rng = np.random.default_rng(7 + rank)
     for b in range(args.batch):
@@ -83,8 +91,9 @@ def build_inputs(args, rank, world):
         pts = sc["pts3d"].copy()
         if world > 1 or b >= 2:  # every rank / problem owns a different jittered sample of the same plane
             pts = pts + rng.normal(0, 1e-3, pts.shape) * np.array([[1.0], [1.0], [0.0]])
-        batch.Set3Dpoints(b, np.ascontiguousarray(pts))
-    return dict(ic=ic, op=op, cam=cam, batch=batch, pyrs=pyrs, scenes=scenes, n_pts=n_pts)
+        for e in engines:
+            e.Set3Dpoints(b, np.ascontiguousarray(pts.copy()))
+    return dict(ic=ic, op=op, cam=cam, batch=engines[0], engines=engines, pyrs=pyrs, scenes=scenes, n_pts=n_pts)
 
 
 def cpu_baseline(args, scene, n_pts):
@@ -138,13 +147,16 @@ def main():
     inp = build_inputs(args, rank, world)
     batch, op, pyrs, scenes = inp["batch"], inp["op"], inp["pyrs"], inp["scenes"]
     B, P, n_pts = args.batch, args.psz, inp["n_pts"]
-    batch.set_variant(args.variant)
+    engines = inp["engines"]
+    for e in engines:
+        e.set_variant(args.variant)
     tracker = None
     if world > 1:
         from invcompcamtrack_amd.dist import ShardedTracker
         tracker = ShardedTracker(batch, staged=args.rehearse_gloo)
     elif not args.no_events:
-        batch.set_timing(True)
+        for e in engines:
+            e.set_timing(True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -152,32 +164,74 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        for b in range(B):
-            pa, pb = pyrs[b]
-            batch.SetPose(b, scenes[b % 2]["p_a"], pa, pb)
-        if tracker is not None:
-            tracker.track()
-        else:
-            batch.track_async()
-        return batch.poses()  # waits for the stream, poses on the host
-
-    for _ in range(args.warmup):
-        poses = step()
     ev_setup = np.zeros(args.levels)
     ev_iters = np.zeros(args.levels)
     ev_kernel = np.zeros(args.levels)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses = step()
-        if tracker is None and not args.no_events:
-            a, b_ = batch.level_times()
+
+    host_t = {"setpose": 0.0, "enqueue": 0.0, "wait_poses": 0.0, "read_events": 0.0}  # host-side phases (stderr)
+
+    def enqueue(i):
+        """Hand step i (one batch of B frame pairs) to the GPU; returns the engine that holds it."""
+        eng = engines[i % len(engines)]
+        t_a = time.perf_counter()
+        for b in range(B):
+            pa, pb = pyrs[b]
+            eng.SetPose(b, scenes[b % 2]["p_a"], pa, pb)
+        t_b = time.perf_counter()
+        if tracker is not None:
+            tracker.track()
+        else:
+            eng.track_async()
+        host_t["setpose"] += t_b - t_a
+        host_t["enqueue"] += time.perf_counter() - t_b
+        return eng
+
+    def collect(eng, timed):
+        """Wait for that engine's tracking and fetch its poses (and, in the timed region, its event timings)."""
+        nonlocal ev_setup, ev_iters, ev_kernel
+        t_a = time.perf_counter()
+        poses = eng.poses()
+        t_b = time.perf_counter()
+        if timed and tracker is None and not args.no_events:
+            a, b_ = eng.level_times()
             ev_setup += a
             ev_iters += b_
-            ev_kernel += batch.kernel_times()
+            ev_kernel += eng.kernel_times()
+        host_t["wait_poses"] += t_b - t_a
+        host_t["read_events"] += time.perf_counter() - t_b
+        return poses
+
+    def run(nsteps, timed):
+        poses, pending = None, None
+        for i in range(nsteps):
+            eng = enqueue(i)
+            if len(engines) == 1:
+                poses = collect(eng, timed)
+            else:
+                if pending is not None:
+                    poses = collect(pending, timed)
+                pending = eng
+        if pending is not None:
+            poses = collect(pending, timed)
+        return poses
+
+    run(args.warmup, False)
+    barrier()
+    for k in host_t:
+        host_t[k] = 0.0
+    # a generation-2 collection of the Python GC costs ~40 ms with torch imported and used to land inside the timed
+    # steps (one 42 ms stall of the SetPose loop per run): collect now, keep the collector off while timing
+    import gc
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    poses = run(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if rank == 0:
+        print("[bench] host ms per step: " + ", ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in host_t.items()),
+              file=sys.stderr, flush=True)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -209,6 +263,7 @@ def main():
                        "frame_pairs_per_step_per_gpu": B, "points_per_pair_per_gpu": n_pts, "psz": P,
                        "levels": args.levels, "maxiter": args.maxiter, "normdp_ratio": 0.0,
                        "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
+                       "host_pipeline": "2 engines alternate, host one step ahead" if len(engines) == 2 else "none",
                        "parallelism": "single GPU" if world == 1 else f"points sharded x{world}, RCCL all-reduce of "
                                                                       "H (21 f32/level) and b (6 f32/iteration)"},
             "pose_err_vs_ground_truth": err,

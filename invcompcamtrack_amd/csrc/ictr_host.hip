@@ -566,12 +566,23 @@ struct ictr_batch {
   std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
   int evk_iters = 0;
   float *d_red_own = nullptr;
+  // results of the last track_async: the final states are copied to pinned host memory in-stream and an event marks
+  // the end, so that get_poses / the timing getters wait for THIS tracking only and the caller may already have
+  // enqueued the next one on the same stream (another engine): the host runs one step ahead of the GPU
+  ProbState *h_st_pin = nullptr;
+  char *h_up_pin = nullptr;  // pinned staging of the per-tracking uploads (states + plane table): truly asynchronous
+  hipEvent_t done_ev = nullptr, up_ev = nullptr;
+  bool done_valid = false, up_pending = false;
 };
 
 static void batch_free(ictr_batch *b) {
   if (!b) return;
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->evk) (void)hipEventDestroy(e);
+  if (b->done_ev) (void)hipEventDestroy(b->done_ev);
+  if (b->up_ev) (void)hipEventDestroy(b->up_ev);
+  if (b->h_st_pin) (void)hipHostFree(b->h_st_pin);
+  if (b->h_up_pin) (void)hipHostFree(b->h_up_pin);
   b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
@@ -662,6 +673,11 @@ extern "C" int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ic
   alloc((void **)&b->d_planes, sizeof(PlaneSet) * B * L);
   alloc((void **)&b->d_trace, sizeof(ictr_trace_rec) * b->trace_cap);
   alloc((void **)&b->d_trace_count, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_st_pin, sizeof(ProbState) * B, hipHostMallocDefault);
+  if (e == hipSuccess)
+    e = hipHostMalloc((void **)&b->h_up_pin, sizeof(ProbState) * B + sizeof(PlaneSet) * B * L, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->up_ev, hipEventDisableTiming);
   if (e != hipSuccess) {
     batch_free(b);
     return fail(ICTR_ERR_HIP, "batch_create: device allocation failed: %s", hipGetErrorString(e));
@@ -788,6 +804,7 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
   if (int rc = check_op(b->op, b->cam)) return rc;
   if (b->op->maxpttrack != b->M || b->op->psz != b->P || b->op->lv_f + 1 != b->nlev)
     return fail(ICTR_ERR_STATE, "optparam maxpttrack/psz/lv_f changed after creation");
+  b->done_valid = false;
   int maxpts = 0;
   for (int i = 0; i < b->B; ++i) {
     const ProbHost &ph = b->probs[i];
@@ -822,10 +839,19 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
     const int64_t want = (chunks + kWaves - 1) / kWaves;
     const int64_t capx = std::max<int64_t>(1, (int64_t)b->gridx);  // partial buffers are sized for gridx blocks
     b->gridx8 = (int)std::min<int64_t>(std::max<int64_t>(want, 1), capx);
+    if (b->gridx8 >= 64 && !getenv("ICTR_NO_XCD_BANDS"))  // multiple of 8: XCD-aware order (xcd_band_block)
+      b->gridx8 = (int)std::min<int64_t>((b->gridx8 + 7) / 8 * 8, capx / 8 * 8);
   }
-  HIPCHK(hipMemcpyAsync(b->d_st, b->h_st.data(), sizeof(ProbState) * b->B, hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_planes, b->h_planes.data(), sizeof(PlaneSet) * b->h_planes.size(), hipMemcpyHostToDevice,
-                        b->stream));
+  {
+    const size_t nst = sizeof(ProbState) * b->B, npl = sizeof(PlaneSet) * b->h_planes.size();
+    if (b->up_pending) HIPCHK(hipEventSynchronize(b->up_ev));  // the previous upload has left the staging buffer
+    memcpy(b->h_up_pin, b->h_st.data(), nst);
+    memcpy(b->h_up_pin + nst, b->h_planes.data(), npl);
+    HIPCHK(hipMemcpyAsync(b->d_st, b->h_up_pin, nst, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_planes, b->h_up_pin + nst, npl, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipEventRecord(b->up_ev, b->stream));
+    b->up_pending = true;
+  }
   HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));
   if (maxpts > 0) {
     LevelCam cams[16];
@@ -906,7 +932,19 @@ extern "C" int ictr_batch_track_async(ictr_batch *b) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   if (b->sharded) return fail(ICTR_ERR_STATE, "sharded batches are driven phase by phase (see ictr.h)");
   if (int rc = ictr_batch_begin(b)) return rc;
-  return enqueue_levels(b);
+  if (int rc = enqueue_levels(b)) return rc;
+  HIPCHK(hipMemcpyAsync(b->h_st_pin, b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipEventRecord(b->done_ev, b->stream));
+  b->done_valid = true;
+  return ICTR_OK;
+}
+// wait for the engine's last tracking (not for whatever else was enqueued on the stream after it)
+static int batch_wait(ictr_batch *b) {
+  if (b->done_valid)
+    HIPCHK(hipEventSynchronize(b->done_ev));
+  else
+    HIPCHK(hipStreamSynchronize(b->stream));
+  return ICTR_OK;
 }
 
 extern "C" int ictr_batch_set_timing(ictr_batch *b, int enable) {
@@ -925,7 +963,7 @@ extern "C" int ictr_batch_set_timing(ictr_batch *b, int enable) {
 extern "C" int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters) {
   if (!b || !ms_setup || !ms_iters) return fail(ICTR_ERR_INVALID, "get_level_times: NULL argument");
   if (b->ev.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if (int rc = batch_wait(b)) return rc;
   for (int l = 0; l < b->nlev; ++l) {
     ms_setup[l] = ms_iters[l] = 0.0f;
     if (!b->ev_used[l]) continue;
@@ -937,7 +975,7 @@ extern "C" int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float 
 extern "C" int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel) {
   if (!b || !ms_kernel) return fail(ICTR_ERR_INVALID, "get_kernel_times: NULL argument");
   if (b->evk.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if (int rc = batch_wait(b)) return rc;
   const int mi = std::min(b->op->maxiter, b->evk_iters);
   for (int l = 0; l < b->nlev; ++l) {
     ms_kernel[l] = 0.0f;
@@ -957,8 +995,13 @@ extern "C" int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr) {
 }
 
 static int batch_fetch_state(ictr_batch *b) {
-  HIPCHK(hipMemcpyAsync(b->h_st.data(), b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->done_valid) {
+    HIPCHK(hipEventSynchronize(b->done_ev));
+    memcpy(b->h_st.data(), b->h_st_pin, sizeof(ProbState) * b->B);
+  } else {
+    HIPCHK(hipMemcpyAsync(b->h_st.data(), b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
   for (int i = 0; i < b->B; ++i) {
     memcpy(b->probs[i].p, b->h_st[i].p, sizeof(float) * 6);
     memcpy(b->probs[i].G, b->h_st[i].G, sizeof(float) * 12);

@@ -574,6 +574,12 @@ __device__ __forceinline__ float taps_blend(const TapLoads &t, float w0, float w
   return w0 * a + w1 * b + w2 * c + w3 * d;
 }
 
+// XCD-aware workgroup order. The hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its
+// own L2. Re-labelling id -> (id % 8) * (n / 8) + id / 8 gives every XCD a contiguous band of chunks, so neighbouring
+// chunks (which share frame cache lines at their borders) meet in one L2 instead of being fetched twice from the
+// fabric. Needs a grid that is a multiple of 8 (the launchers round up; surplus workgroups find no chunk).
+__device__ __forceinline__ int xcd_band_block(int bx, int gx) { return (gx & 7) ? bx : (bx & 7) * (gx >> 3) + (bx >> 3); }
+
 template <int kU>
 struct PatchLoads {  // raw load results of one stage-2 step of kU patches (consumers belong to the reduce phase)
   float t[kU], gx[kU], gy[kU];
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
 
   const int nchunks = (npts + cpw - 1) / cpw;
-  for (int ch = blockIdx.x * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+  for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
     const int i0 = ch * cpw;
     const int cnt = min(cpw, npts - i0);
     // ---- stage 1: lane j <-> point i0 + j  (step 7, pose.cpp:384-391; ind_new, odometer.cpp:369-377)
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
 
   const int nchunks = (npts + cpw - 1) / cpw;
-  for (int ch = blockIdx.x * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+  for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
     const int i0 = ch * cpw;
     const int cnt = min(cpw, npts - i0);
     // ---- stage 1: one point per lane: visibility (odometer.cpp:273-282), sd coefficients (:313-326)

@@ -76,7 +76,7 @@ class AlignBatch:
             check(_lib.load().ictr_icgn_set_stream(self._h, C.c_void_p(stream)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "load", None):
             _lib.load().ictr_icgn_destroy(self._h)
             self._h = None
 

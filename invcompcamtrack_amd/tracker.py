@@ -49,7 +49,7 @@ class CamClass:
                                 self._wh.ctypes.data_as(_lib.IP), padding))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "load", None):
             _lib.load().ictr_cam_destroy(self._h)
             self._h = None
 
@@ -91,7 +91,7 @@ class Pyramid:
         self.w, self.h = w, h
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "load", None):
             _lib.load().ictr_pyramid_destroy(self._h)
             self._h = None
 
@@ -183,7 +183,7 @@ class PoseClass:
         check(_lib.load().ictr_pose_create(C.byref(self._h), camobj._h, C.byref(op)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "load", None):
             _lib.load().ictr_pose_destroy(self._h)
             self._h = None
 
@@ -236,7 +236,7 @@ class OdometerClass:
         check(_lib.load().ictr_odometer_create(C.byref(self._h), pose_in._h, C.byref(op_in)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "load", None):
             _lib.load().ictr_odometer_destroy(self._h)
             self._h = None
 
@@ -320,7 +320,7 @@ class TrackBatch:
         check(_lib.load().ictr_batch_create(C.byref(self._h), camobj._h, C.byref(op), nproblems))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "load", None):
             _lib.load().ictr_batch_destroy(self._h)
             self._h = None
 
