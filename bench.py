@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one engine, host and GPU strictly alternate (the pre-pipelining behaviour)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="sharded mode: groups of pairs pipelined against each other's collectives (0 = time 1 and 2)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 code path (sharded phases + collectives) with a world of 1 (testing)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on ONE GPU: all ranks use cuda:0 and the 27*B floats are all-reduced through "
                          "host memory with gloo (same kernels, same phase sequence; numbers are not a benchmark)")
@@ -76,24 +80,34 @@ def build_inputs(args, rank, world):
     n_pts = scenes[0]["pts3d"].shape[1]
     op = ic.optparam(lv_f, 0, P, args.maxiter, 0.0, 0, 0, n_pts)
     cam = ic.CamClass(lv_f + 1, scenes[0]["fc"], scenes[0]["cc"], scenes[0]["wh"], P)
-    # Two engines take the steps in turn on one stream (single-GPU mode): while the GPU runs step i on one, the host
-    # prepares and enqueues step i+1 on the other, then collects step i's poses (each engine waits for its own
-    # end-of-tracking event only). Kernels never overlap; the GPU just does not idle during the host's SetPose work.
-    n_eng = 1 if (world > 1 or args.no_pipeline) else 2
-    engines = [ic.TrackBatch(cam, op, args.batch) for _ in range(n_eng)]
-    pyrs = []
+    pyrs, points = [], []
     rng = np.random.default_rng(7 + rank)
     for b in range(args.batch):
         sc = scenes[b % 2]
-        pa = ic.Pyramid(sc["img_a"], lv_f, P)
-        pb = ic.Pyramid(sc["img_b"], lv_f, P)
-        pyrs.append((pa, pb))
+        pyrs.append((ic.Pyramid(sc["img_a"], lv_f, P), ic.Pyramid(sc["img_b"], lv_f, P)))
         pts = sc["pts3d"].copy()
         if world > 1 or b >= 2:  # every rank / problem owns a different jittered sample of the same plane
             pts = pts + rng.normal(0, 1e-3, pts.shape) * np.array([[1.0], [1.0], [0.0]])
-        for e in engines:
-            e.Set3Dpoints(b, np.ascontiguousarray(pts.copy()))
-    return dict(ic=ic, op=op, cam=cam, batch=engines[0], engines=engines, pyrs=pyrs, scenes=scenes, n_pts=n_pts)
+        points.append(np.ascontiguousarray(pts))
+
+    def make_engines(n_parts, split):
+        """split=False: n_parts engines that each hold all B pairs (they take the steps in turn);
+        split=True: the B pairs divided into n_parts groups (sharded mode)."""
+        per = args.batch // n_parts if split else args.batch
+        engs = [ic.TrackBatch(cam, op, per) for _ in range(n_parts)]
+        for b in range(args.batch):
+            if split:
+                engs[b // per].Set3Dpoints(b % per, points[b].copy())
+            else:
+                for e in engs:
+                    e.Set3Dpoints(b, points[b].copy())
+        for e in engs:
+            e.set_variant(args.variant)
+            if not args.no_events:
+                e.set_timing(True)
+        return engs
+
+    return dict(ic=ic, op=op, cam=cam, make_engines=make_engines, pyrs=pyrs, scenes=scenes, n_pts=n_pts)
 
 
 def cpu_baseline(args, scene, n_pts):
@@ -125,6 +139,12 @@ def cpu_baseline(args, scene, n_pts):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout. Native libraries write there too (RCCL prints a five-line version
+    # banner on its first collective), so everything that goes to fd 1 during the run is sent to stderr and the
+    # result line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +158,11 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.force_sharded:
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -145,18 +170,18 @@ def main():
     _lib.check(_lib.load().ictr_set_device(local_rank if world > 1 else 0))
 
     inp = build_inputs(args, rank, world)
-    batch, op, pyrs, scenes = inp["batch"], inp["op"], inp["pyrs"], inp["scenes"]
+    op, pyrs, scenes = inp["op"], inp["pyrs"], inp["scenes"]
     B, P, n_pts = args.batch, args.psz, inp["n_pts"]
-    engines = inp["engines"]
-    for e in engines:
-        e.set_variant(args.variant)
+    sharded = world > 1 or args.force_sharded
     tracker = None
-    if world > 1:
+    if sharded:
         from invcompcamtrack_amd.dist import ShardedTracker
-        tracker = ShardedTracker(batch, staged=args.rehearse_gloo)
-    elif not args.no_events:
-        for e in engines:
-            e.set_timing(True)
+        engines = None  # chosen below (group-count autotuning)
+    else:
+        # Two engines take the steps in turn on one stream: while the GPU runs step i on one, the host prepares and
+        # enqueues step i+1 on the other, then collects step i's poses (each engine waits for its own end-of-tracking
+        # event only). Kernels never overlap; the GPU just does not idle during the host's SetPose / enqueue work.
+        engines = inp["make_engines"](1 if args.no_pipeline else 2, split=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,11 +197,15 @@ def main():
 
     def enqueue(i):
         """Hand step i (one batch of B frame pairs) to the GPU; returns the engine that holds it."""
-        eng = engines[i % len(engines)]
+        eng = tracker if tracker is not None else engines[i % len(engines)]
         t_a = time.perf_counter()
         for b in range(B):
             pa, pb = pyrs[b]
-            eng.SetPose(b, scenes[b % 2]["p_a"], pa, pb)
+            if tracker is not None:
+                per = B // len(engines)
+                engines[b // per].SetPose(b % per, scenes[b % 2]["p_a"], pa, pb)
+            else:
+                eng.SetPose(b, scenes[b % 2]["p_a"], pa, pb)
         t_b = time.perf_counter()
         if tracker is not None:
             tracker.track()
@@ -192,11 +221,12 @@ def main():
         t_a = time.perf_counter()
         poses = eng.poses()
         t_b = time.perf_counter()
-        if timed and tracker is None and not args.no_events:
-            a, b_ = eng.level_times()
-            ev_setup += a
-            ev_iters += b_
-            ev_kernel += eng.kernel_times()
+        if timed and not args.no_events:
+            for e_ in (engines if tracker is not None else [eng]):
+                a, b_ = e_.level_times()  # zeros in the sharded (phase-driven) mode
+                ev_setup += a
+                ev_iters += b_
+                ev_kernel += e_.kernel_times()
         host_t["wait_poses"] += t_b - t_a
         host_t["read_events"] += time.perf_counter() - t_b
         return poses
@@ -205,7 +235,7 @@ def main():
         poses, pending = None, None
         for i in range(nsteps):
             eng = enqueue(i)
-            if len(engines) == 1:
+            if len(engines) == 1 or tracker is not None:
                 poses = collect(eng, timed)
             else:
                 if pending is not None:
@@ -214,6 +244,34 @@ def main():
         if pending is not None:
             poses = collect(pending, timed)
         return poses
+
+    tuning = None
+    if sharded:
+        # Sharded mode: one group of B pairs exposes every all-reduce; two groups of B/2 hide each other's
+        # collectives behind compute (dist.sharded_program) but pay the per-iteration tail/finish launches twice.
+        # Which wins depends on the collective's latency on this node, so both are timed (2 steps each, max over
+        # ranks) before the warm-up and the faster one is used.
+        cands = [args.groups] if args.groups else ([1, 2] if (B % 2 == 0 and B >= 2) else [1])
+        built, tuning = {}, {}
+        for g in cands:
+            engines = inp["make_engines"](g, split=True)
+            tracker = ShardedTracker(engines, staged=args.rehearse_gloo)
+            built[g] = (engines, tracker)
+            if len(cands) > 1:
+                run(1, False)
+                barrier()
+                t_a = time.perf_counter()
+                run(2, False)
+                barrier()
+                t_g = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64,
+                                   device="cpu" if args.rehearse_gloo else "cuda")
+                dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
+                tuning[g] = float(t_g.item()) / 2 * 1e3
+        best = min(tuning, key=tuning.get) if tuning else cands[0]
+        engines, tracker = built[best]
+        built.clear()
+        if rank == 0 and tuning:
+            print(f"[bench] group-count tuning (ms/step): {tuning} -> {best}", file=sys.stderr, flush=True)
 
     run(args.warmup, False)
     barrier()
@@ -263,23 +321,28 @@ def main():
                        "frame_pairs_per_step_per_gpu": B, "points_per_pair_per_gpu": n_pts, "psz": P,
                        "levels": args.levels, "maxiter": args.maxiter, "normdp_ratio": 0.0,
                        "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
-                       "host_pipeline": "2 engines alternate, host one step ahead" if len(engines) == 2 else "none",
-                       "parallelism": "single GPU" if world == 1 else f"points sharded x{world}, RCCL all-reduce of "
+                       "host_pipeline": ("2 engines alternate, host one step ahead" if (len(engines) == 2 and tracker is None)
+                                         else "none"),
+                       "collective_overlap": (f"{len(engines)} group(s) of pairs per rank (groups hide each other's "
+                                              f"all-reduces); tuning ms/step: {tuning}" if tracker is not None else "n/a"),
+                       "parallelism": "single GPU" if (world == 1 and tracker is None) else f"points sharded x{world}, RCCL all-reduce of "
                                                                       "H (21 f32/level) and b (6 f32/iteration)"},
             "pose_err_vs_ground_truth": err,
         }
-        if tracker is None and not args.no_events:
-            nl = args.steps * args.maxiter
+        if not args.no_events:
             # the dominant kernel = the GN-iteration accumulate kernel (k_iter8): every launch, at every level, processes
-            # the same B x N x 64 pixels, so its mean duration over ALL launches is what rocprofv3 --stats reports too
-            t_kernel = float(ev_kernel.sum()) / (nl * args.levels) * 1e-3   # s per launch, kernel alone
-            alg = 16.0 * pix_per_iter * B
+            # the same pairs x N x 64 pixels, so its mean duration over ALL launches is what rocprofv3 --stats reports too
+            pairs_per_launch = engines[0].B            # B, or B/2 per group in the sharded mode
+            launches_per_step_level = args.maxiter * (len(engines) if tracker is not None else 1)
+            nl = args.steps * launches_per_step_level
+            t_kernel = float(ev_kernel.sum()) / (nl * args.levels) * 1e-3   # s per launch, kernel alone (rank 0)
+            alg = 16.0 * pix_per_iter * pairs_per_launch
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("batch") == B and tj.get("points") == n_pts:
+                    if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts and tracker is None:
                         traffic = tj.get("hbm_bytes_per_launch_mean")
                 except Exception:
                     traffic = None
@@ -288,13 +351,16 @@ def main():
                                "kernel": "k_iter8 (GN iteration: steps 7-9a), mean over all launches of the timed steps",
                                "algorithmic_bytes_per_launch": alg, "us_per_launch": t_kernel * 1e6,
                                "per_level_kernel_us": [float(x) / nl * 1e3 for x in ev_kernel],
-                               "per_level_us_per_iteration_incl_tail_and_gaps": [float(x) / nl * 1e3 for x in ev_iters],
-                               "per_level_setup_us": [float(x) / args.steps * 1e3 for x in ev_setup]}
+                               "per_level_us_per_iteration_incl_tail_and_gaps":
+                                   [float(x) / nl * 1e3 for x in ev_iters] if tracker is None else None,
+                               "per_level_setup_us":
+                                   [float(x) / args.steps * 1e3 for x in ev_setup] if tracker is None else None}
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, scenes[0], n_pts)
-        elif world > 1:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        else:
+            out["cpu_baseline"] = None  # measured on rank 0 at N=1 only
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -565,6 +565,7 @@ struct ictr_batch {
   std::vector<char> ev_used;
   std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
   int evk_iters = 0;
+  int phase_it = 0;  // iteration counter of the phase API (event slot of the next iter_accumulate)
   float *d_red_own = nullptr;
   // results of the last track_async: the final states are copied to pinned host memory in-stream and an event marks
   // the end, so that get_poses / the timing getters wait for THIS tracking only and the caller may already have
@@ -805,6 +806,8 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
   if (b->op->maxpttrack != b->M || b->op->psz != b->P || b->op->lv_f + 1 != b->nlev)
     return fail(ICTR_ERR_STATE, "optparam maxpttrack/psz/lv_f changed after creation");
   b->done_valid = false;
+  b->phase_it = 0;
+  if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
   int maxpts = 0;
   for (int i = 0; i < b->B; ++i) {
     const ProbHost &ph = b->probs[i];
@@ -884,13 +887,25 @@ extern "C" int ictr_batch_level_accumulate(ictr_batch *b, int level) {
 }
 extern "C" int ictr_batch_level_finish(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
+  b->phase_it = 0;
   if (b->sharded) launch_level_finish(engine_dev(b), b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
 extern "C" int ictr_batch_iter_accumulate(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
-  launch_iter(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+  // with timing on, HIP events bracket the accumulate kernel alone, as in the fused run (get_kernel_times)
+  const bool tk = b->timing && b->phase_it < b->evk_iters && (int)b->evk.size() >= 2 * b->nlev * b->evk_iters;
+  const EngineDev e = engine_dev(b);
+  const LevelCam lc = level_cam(b->cam, level);
+  if (tk) HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it)], b->stream));
+  launch_iter_main(e, lc, level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+  if (tk) {
+    HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it) + 1], b->stream));
+    if (b->phase_it + 1 == std::min(b->op->maxiter, b->evk_iters)) b->ev_used[level] = 2;  // kernel events complete
+  }
+  b->phase_it++;
+  launch_iter_tail(e, level, b->gridx, b->variant, b->gridx8, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -966,7 +981,7 @@ extern "C" int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float 
   if (int rc = batch_wait(b)) return rc;
   for (int l = 0; l < b->nlev; ++l) {
     ms_setup[l] = ms_iters[l] = 0.0f;
-    if (!b->ev_used[l]) continue;
+    if (b->ev_used[l] != 1) continue;
     HIPCHK(hipEventElapsedTime(&ms_setup[l], b->ev[3 * l + 0], b->ev[3 * l + 1]));
     HIPCHK(hipEventElapsedTime(&ms_iters[l], b->ev[3 * l + 1], b->ev[3 * l + 2]));
   }

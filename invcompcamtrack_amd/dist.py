@@ -61,30 +61,84 @@ def run_sharded_levels(engine, op, allreduce):
             engine.iter_finish(sl)      # steps 9b-10, identical on every rank
 
 
+def sharded_program(engine, op, allreduce_async):
+    """The same loop as a generator that yields right after every collective has been STARTED and waits for it
+    when it is resumed. Several such programs (one per group of problems) run round-robin
+    (``run_interleaved``): while group A's 27 floats per problem travel, group B's accumulate kernel runs, so the
+    collective latency is hidden behind compute instead of adding to every Gauss-Newton iteration.
+    ``allreduce_async()`` starts the reduction of the engine's buffer and returns an object with ``wait()``."""
+    engine.begin()
+    for sl in range(op.lv_f, op.lv_l - 1, -1):
+        engine.level_accumulate(sl)
+        h = allreduce_async()
+        yield
+        h.wait()
+        engine.level_finish(sl)
+        for _ in range(op.maxiter):
+            engine.iter_accumulate(sl)
+            h = allreduce_async()
+            yield
+            h.wait()
+            engine.iter_finish(sl)
+
+
+def run_interleaved(programs):
+    """Round-robin over generator programs until all are exhausted."""
+    active = list(programs)
+    while active:
+        for p in list(active):
+            try:
+                next(p)
+            except StopIteration:
+                active.remove(p)
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
 class ShardedTracker:
+    """Drives one TrackBatch, or several (groups of problems that are software-pipelined against each other's
+    collectives), in sharded mode. With the nccl (= RCCL) backend the all-reduce is asynchronous: it runs on the
+    communicator's stream and ``wait()`` makes the compute stream wait, not the host."""
+
     def __init__(self, batch, group=None, staged=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
-        self.batch, self.group, self.staged = batch, group, staged
-        batch.enable_sharding(True)
-        self.red = torch.zeros(batch.B * RED_STRIDE, dtype=torch.float32, device="cuda")
-        batch.set_reduction_buffer(self.red.data_ptr())
-        batch.set_stream(torch.cuda.current_stream().cuda_stream)
-        self._host = torch.zeros(batch.B * RED_STRIDE, dtype=torch.float32) if staged else None
+        self.batches = list(batch) if isinstance(batch, (list, tuple)) else [batch]
+        self.batch = self.batches[0]
+        self.group, self.staged = group, staged
+        self.reds, self._hosts = [], []
+        for b in self.batches:
+            b.enable_sharding(True)
+            red = torch.zeros(b.B * RED_STRIDE, dtype=torch.float32, device="cuda")
+            b.set_reduction_buffer(red.data_ptr())
+            b.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.reds.append(red)
+            self._hosts.append(torch.zeros(b.B * RED_STRIDE, dtype=torch.float32) if staged else None)
+        self.red = self.reds[0]
 
-    def _allreduce(self):
+    def _allreduce_async(self, g):
         dist = self._dist
         if self.staged:
-            self._host.copy_(self.red)  # synchronises with the current stream
-            dist.all_reduce(self._host, op=dist.ReduceOp.SUM, group=self.group)
-            self.red.copy_(self._host)
-        else:
-            dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.group)
+            self._hosts[g].copy_(self.reds[g])  # synchronises with the current stream
+            dist.all_reduce(self._hosts[g], op=dist.ReduceOp.SUM, group=self.group)
+            self.reds[g].copy_(self._hosts[g])
+            return _Done()
+        return dist.all_reduce(self.reds[g], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _allreduce(self):  # the synchronous single-group form (kept for callers of run_sharded_levels)
+        self._allreduce_async(0).wait()
 
     def track(self):
         """Enqueue the whole tracking of all problems; returns without synchronising (unless staged)."""
-        run_sharded_levels(self.batch, self.batch.op, self._allreduce)
+        if len(self.batches) == 1:
+            run_sharded_levels(self.batch, self.batch.op, self._allreduce)
+        else:
+            run_interleaved([sharded_program(b, b.op, (lambda g=g: self._allreduce_async(g)))
+                             for g, b in enumerate(self.batches)])
 
     def poses(self):
-        return self.batch.poses()
+        return np.concatenate([b.poses() for b in self.batches], 0)

@@ -105,6 +105,71 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_interleaved(rank, world, port, q):
+    """Two groups (two different scenes) software-pipelined against each other's ASYNCHRONOUS all-reduces."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from invcompcamtrack_amd import synth
+    from invcompcamtrack_amd.dist import run_interleaved, shard_slices, sharded_program
+    from oracle import np_oracle as N
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lv_f, psz, maxiter = 1, 8, 3
+    engs, order = [], []
+    for g, seed in enumerate((12, 13)):
+        sc = synth.make_scene(256, 192, n_points=45, seed=seed, margin=40.0)
+        lo, hi = shard_slices(45, world)[rank]
+        engs.append(NumpyShardEngine(O, N, sc, lo, hi, lv_f, psz, maxiter))
+    op = O.make_op(lv_f, 0, psz, maxiter, 0.0, 0, 0, 64)
+
+    def ar(g):
+        order.append(("start", g))
+        t = torch.from_numpy(engs[g].red)
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+        class H:
+            def wait(self_inner):
+                order.append(("wait", g))
+                w.wait()
+        return H()
+
+    run_interleaved([sharded_program(e, op, (lambda g=g: ar(g))) for g, e in enumerate(engs)])
+    q.put((rank, [e.p.copy() for e in engs], order))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_interleaved_groups_overlap_collectives_gloo(oracle):
+    import torch.multiprocessing as mp
+    from invcompcamtrack_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_interleaved, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, pa, order0), (_, pb, order1) = res
+    assert order0 == order1
+    # the schedule: group 1's collective is started before group 0's is waited for, every time
+    assert order0[:4] == [("start", 0), ("start", 1), ("wait", 0), ("start", 0)]
+    assert len(order0) == 2 * 2 * 2 * (1 + 3)          # start+wait x groups x levels x (1 + maxiter)
+    for g, seed in enumerate((12, 13)):
+        assert np.array_equal(pa[g], pb[g])
+        sc = synth.make_scene(256, 192, n_points=45, seed=seed, margin=40.0)
+        op = oracle.make_op(1, 0, 8, 3, 0.0, 0, 0, 45)
+        tr = oracle.Tracker(op, sc["fc"], sc["cc"], sc["wh"])
+        tr.set3dpoints(sc["pts3d"].copy())
+        tr.setpose(sc["p_a"], oracle.Pyramid(sc["img_a"], 1, 8), oracle.Pyramid(sc["img_b"], 1, 8))
+        tr.trackpose()
+        assert np.allclose(pa[g], tr.pose_p(), atol=2e-5)
+
+
 @pytest.mark.timeout(300)
 def test_sharded_loop_two_ranks_gloo(oracle):
     import torch.multiprocessing as mp
