@@ -212,7 +212,10 @@ float *ictr_batch_reduction_buffer(ictr_batch *b); /* device pointer, nproblems*
 /* use a caller-owned device buffer (e.g. a torch tensor handed to torch.distributed) instead; NULL = internal */
 int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr);
 int ictr_batch_begin(ictr_batch *b);                  /* SetPose projection, all problems */
-int ictr_batch_level_accumulate(ictr_batch *b, int level);  /* steps 4-6 -> local H in red[] */
+/* 1 if the caller must all-reduce red[] between level_accumulate and level_finish; 0 on the 8x8 fast path, where H
+ * is accumulated by the level's first iteration launch and travels with that iteration's b (27 floats, one message) */
+int ictr_batch_level_allreduce_needed(ictr_batch *b);
+int ictr_batch_level_accumulate(ictr_batch *b, int level);  /* steps 4-6 -> local H in red[] (unless deferred) */
 int ictr_batch_level_finish(ictr_batch *b, int level);      /* adopt (reduced) H, reset iteration state */
 int ictr_batch_iter_accumulate(ictr_batch *b, int level);   /* steps 7-9a -> local b in red[] */
 int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on the (reduced) b */

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ictr_batch_enable_sharding": (C.c_int, [VP, C.c_int]),
     "ictr_batch_reduction_buffer": (VP, [VP]),
     "ictr_batch_begin": (C.c_int, [VP]),
+    "ictr_batch_level_allreduce_needed": (C.c_int, [VP]),
     "ictr_batch_level_accumulate": (C.c_int, [VP, C.c_int]),
     "ictr_batch_level_finish": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_accumulate": (C.c_int, [VP, C.c_int]),

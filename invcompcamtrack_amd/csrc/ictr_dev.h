@@ -26,6 +26,7 @@ struct LevelCam {
 // device pointers of the four planes one problem reads at one level
 struct PlaneSet {
   const float *ref, *dx, *dy, *cur;
+  const float *pack;  // optional: the reference level as one interleaved plane {img, dx, dy, 0} per pixel (k_ref8)
 };
 
 // per-problem state living in device memory for the whole coarse-to-fine loop
@@ -61,6 +62,7 @@ struct EngineDev {
   float ratio;
   int dopatchnorm;
   int sharded;  // 1: accumulate kernels stop after writing rank-local sums to red[]
+  int packed;   // 1: every problem's reference pyramid carries the interleaved {img, dx, dy, 0} planes
   float *pt3d;      // [B][3M]  X..Y..Z..
   float *pt3d_ref;  // [B][3M]  camera-frame points at the reference pose
   float *pt2d;      // [B][nlev][2M]

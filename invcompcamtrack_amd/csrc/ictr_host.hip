@@ -19,16 +19,18 @@ namespace ictr {
 void launch_pyr_copy(const float *, float *, int, int, int, int, hipStream_t);
 void launch_pyr_down(const float *, int, int, int, float *, int, int, int, int, hipStream_t);
 void launch_pyr_finish(float *, float *, float *, int, int, int, int, int, int, hipStream_t);
+void launch_pyr_pack(const float *, const float *, const float *, float *, size_t, hipStream_t);
 void launch_getpatch(const float *, const float *, const float *, const float *, int, int, int, int, float *, float *,
                      float *, hipStream_t);
 void launch_project_generic(const float *, float *, float *, int, int, const float *, LevelCam, hipStream_t);
 void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
 void launch_ref_level(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
-void launch_level_finish(const EngineDev &, hipStream_t);
-void launch_iter(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
-void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
-void launch_iter_tail(const EngineDev &, int, int, int, int, hipStream_t);
-void launch_iter_finish(const EngineDev &, int, hipStream_t);
+void launch_level_finish(const EngineDev &, int, hipStream_t);
+void launch_iter(const EngineDev &, const LevelCam &, int, int, int, int, int, int, hipStream_t);
+void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, int, int, hipStream_t);
+void launch_iter_tail(const EngineDev &, int, int, int, int, int, hipStream_t);
+void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
+bool defer_h(const EngineDev &, int);
 }  // namespace ictr
 
 namespace ictr {
@@ -221,6 +223,7 @@ struct ictr_pyramid {
   int nlev = 0, pad = 0, w0 = 0, h0 = 0, getgrad = 0;
   std::vector<int> w, h, sw, sh;
   std::vector<float *> img, dx, dy;  // device planes
+  std::vector<float *> pack;         // with gradients: the level again as interleaved {img, dx, dy, 0} texels
   float *arena = nullptr;
 };
 
@@ -281,7 +284,7 @@ static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad
     p->sh.push_back(hl + 2 * pad);
     size_t plane = (size_t)(wl + 2 * pad) * (hl + 2 * pad);
     plane = (plane + 63) / 64 * 64;  // 256-B aligned planes
-    total += plane * 3;
+    total += plane * (getgrad ? 7 : 3);
   }
   hipError_t e = hipMalloc((void **)&p->arena, total * sizeof(float));
   if (e != hipSuccess) {
@@ -295,7 +298,8 @@ static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad
     p->img.push_back(cur);
     p->dx.push_back(cur + plane);
     p->dy.push_back(cur + 2 * plane);
-    cur += 3 * plane;
+    p->pack.push_back(getgrad ? cur + 3 * plane : nullptr);
+    cur += (getgrad ? 7 : 3) * plane;
   }
   *out = p;
   return ICTR_OK;
@@ -309,6 +313,7 @@ static int pyramid_build(ictr_pyramid *p, const float *img_dev, hipStream_t s) {
       launch_pyr_down(p->img[l - 1], p->w[l - 1], p->h[l - 1], p->sw[l - 1], p->img[l], p->w[l], p->h[l], p->pad,
                       p->sw[l], s);
     launch_pyr_finish(p->img[l], p->dx[l], p->dy[l], p->w[l], p->h[l], p->pad, p->sw[l], p->sh[l], p->getgrad, s);
+    if (p->getgrad) launch_pyr_pack(p->img[l], p->dx[l], p->dy[l], p->pack[l], (size_t)p->sw[l] * p->sh[l], s);
   }
   HIPCHK(hipGetLastError());
   return ICTR_OK;
@@ -363,6 +368,11 @@ extern "C" int ictr_pyramid_create_from_host_planes(ictr_pyramid **out, const fl
       ictr_pyramid_destroy(p);
       return fail(ICTR_ERR_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
     }
+    if (p->getgrad) launch_pyr_pack(p->img[l], p->dx[l], p->dy[l], p->pack[l], (size_t)p->sw[l] * p->sh[l], nullptr);
+  }
+  if (p->getgrad && hipStreamSynchronize(nullptr) != hipSuccess) {
+    ictr_pyramid_destroy(p);
+    return fail(ICTR_ERR_HIP, "pyramid: packing kernels failed");
   }
   *out = p;
   return ICTR_OK;
@@ -565,6 +575,7 @@ struct ictr_batch {
   std::vector<char> ev_used;
   std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
   int evk_iters = 0;
+  int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
   int phase_it = 0;  // iteration counter of the phase API (event slot of the next iter_accumulate)
   float *d_red_own = nullptr;
   // results of the last track_async: the final states are copied to pinned host memory in-stream and an event marks
@@ -605,6 +616,7 @@ static EngineDev engine_dev(const ictr_batch *b) {
   e.ratio = b->op->normdp_ratio;
   e.dopatchnorm = b->op->dopatchnorm ? 1 : 0;
   e.sharded = b->sharded;
+  e.packed = b->packed;
   e.pt3d = b->d_pt3d;
   e.pt3d_ref = b->d_pt3d_ref;
   e.pt2d = b->d_pt2d;
@@ -807,6 +819,7 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
     return fail(ICTR_ERR_STATE, "optparam maxpttrack/psz/lv_f changed after creation");
   b->done_valid = false;
   b->phase_it = 0;
+  bool all_packed = true;
   if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
   int maxpts = 0;
   for (int i = 0; i < b->B; ++i) {
@@ -825,8 +838,11 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
       ps.dx = ph.ref->dx[l];
       ps.dy = ph.ref->dy[l];
       ps.cur = ph.cur->img[l];
+      ps.pack = ph.ref->pack[l];
+      if (!ps.pack) all_packed = false;
     }
   }
+  b->packed = all_packed ? 1 : 0;
   {
     // P=8 fast path geometry: a wave owns `cpw` consecutive points. Small problems get small chunks (more
     // waves, latency hidden by occupancy); large batches get 64-point chunks (coalesced stage 1, deep ILP).
@@ -879,8 +895,15 @@ static int level_ok(ictr_batch *b, int level) {
   if (level < b->op->lv_l || level > b->op->lv_f) return fail(ICTR_ERR_INVALID, "level out of range");
   return ICTR_OK;
 }
+// 1: the level phase leaves a partial H in the reduction buffer that must be summed over ranks before level_finish;
+// 0 (P = 8 fast path, deferred H): H travels with the first iteration's b, the level phase needs no collective
+extern "C" int ictr_batch_level_allreduce_needed(ictr_batch *b) {
+  if (!b) return 1;
+  return defer_h(engine_dev(b), b->variant) ? 0 : 1;
+}
 extern "C" int ictr_batch_level_accumulate(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
+  b->phase_it = 0;
   launch_ref_level(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
@@ -888,7 +911,7 @@ extern "C" int ictr_batch_level_accumulate(ictr_batch *b, int level) {
 extern "C" int ictr_batch_level_finish(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
   b->phase_it = 0;
-  if (b->sharded) launch_level_finish(engine_dev(b), b->stream);
+  if (b->sharded) launch_level_finish(engine_dev(b), b->variant, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -899,19 +922,20 @@ extern "C" int ictr_batch_iter_accumulate(ictr_batch *b, int level) {
   const EngineDev e = engine_dev(b);
   const LevelCam lc = level_cam(b->cam, level);
   if (tk) HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it)], b->stream));
-  launch_iter_main(e, lc, level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+  const int first = b->phase_it == 0;
+  launch_iter_main(e, lc, level, b->gridx, b->variant, b->cpw, b->gridx8, first, b->stream);
   if (tk) {
     HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it) + 1], b->stream));
     if (b->phase_it + 1 == std::min(b->op->maxiter, b->evk_iters)) b->ev_used[level] = 2;  // kernel events complete
   }
   b->phase_it++;
-  launch_iter_tail(e, level, b->gridx, b->variant, b->gridx8, b->stream);
+  launch_iter_tail(e, level, b->gridx, b->variant, b->gridx8, first, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
 extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
-  if (b->sharded) launch_iter_finish(engine_dev(b), level, b->stream);
+  if (b->sharded) launch_iter_finish(engine_dev(b), level, b->variant, b->phase_it == 1, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -930,9 +954,9 @@ static int enqueue_levels(ictr_batch *b) {
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], b->stream));
     for (int it = 0; it < mi; ++it) {
       if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it)], b->stream));
-      launch_iter_main(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+      launch_iter_main(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, it == 0, b->stream);
       if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it) + 1], b->stream));
-      launch_iter_tail(e, sl, b->gridx, b->variant, b->gridx8, b->stream);
+      launch_iter_tail(e, sl, b->gridx, b->variant, b->gridx8, it == 0, b->stream);
     }
     if (b->timing) {
       HIPCHK(hipEventRecord(b->ev[3 * sl + 2], b->stream));

@@ -24,6 +24,8 @@
 // Arithmetic parity: compiled with -ffp-contract=off; every expression below keeps the reference's
 // operand order, so patches, projections and coefficients are bit-identical to the CPU path; only the
 // order of the big sums differs.
+#include <algorithm>
+
 #include "ictr_dev.h"
 #include "se3_math.h"
 
@@ -318,13 +320,51 @@ __global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, 
 
 // One workgroup per problem: fixed-order f64 reduction of the H partials of `nblk` workgroups (8 slices x 32
 // components, then the slices in order), publish H (or the rank-local sum when sharded), reset the loop state.
-__global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk) {
+// fixed-order f64 reduction of the H partials of `nblk` workgroups into sH[0..20] (all threads of the workgroup)
+__device__ __forceinline__ void reduce_partH(const EngineDev &e, int b, int nblk, double (*sRed)[32], float *sH) {
+  {
+    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double s = 0.0;
+    const float *ph = e.partH + (size_t)b * nblk * kPartHStride + j;
+    if (j < kHUnique)
+      for (int k = sl; k < nblk; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
+    sRed[sl][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kHUnique) {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBlock / 32; ++sl) s += sRed[sl][threadIdx.x];
+    sH[threadIdx.x] = (float)s;
+  }
+  __syncthreads();
+}
+// symmetric 6x6 from the 21 unique entries: st.H and the LDS copy that level_factor destroys
+__device__ __forceinline__ void expand_H(ProbState &st, const float *sH, float *sA) {
+  if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const float v = sH[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    st.H[threadIdx.x] = v;
+    sA[threadIdx.x] = v;
+  }
+  __syncthreads();
+}
+
+// defer_h: the P = 8 fast path accumulates H inside the level's FIRST iteration launch (k_iter8<.., WH = true>: it
+// streams Gx, Gy and the coefficients anyway), so the setup kernel is a pure gather/store kernel and this tail only
+// resets the loop state; the first k_iter_tail / k_iter_finish of the level reduces and factors H.
+__global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk, int defer_h) {
   __shared__ double sRed[kBlock / 32][32];
   __shared__ float sH[32];
   __shared__ float sA[36];
   __shared__ int sI[16];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
+  if (defer_h) {
+    if (threadIdx.x == 0) level_reset(st, e);
+    return;
+  }
   {
     const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
     double s = 0.0;
@@ -360,11 +400,15 @@ __global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk) {
 }
 
 // sharded mode: adopt the all-reduced H (red[b][0..20]) and reset the iteration state
-__global__ void k_level_finish(EngineDev e) {
+__global__ void k_level_finish(EngineDev e, int defer_h) {
   __shared__ float sA[36];
   __shared__ int sI[16];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
+  if (defer_h) {
+    if (threadIdx.x == 0) level_reset(st, e);
+    return;
+  }
   if (threadIdx.x < 36) {
     const int r = threadIdx.x / 6, c = threadIdx.x % 6;
     const int lo = r < c ? r : c, hi = r < c ? c : r;
@@ -476,12 +520,26 @@ __global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int l
 // One workgroup per problem: fixed-order f64 reduction of the b partials (32 slices x 8 components, then the
 // slices in order) and steps 9b-10 (solve, pose update, loop condition) -- or, when the points are sharded over
 // ranks, just the rank-local sum into red[] for the all-reduce.
-__global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, int nblk) {
+__global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, int nblk, int first_h) {
   __shared__ double sRed[kBlock / 8][8];
   __shared__ float sLU[64];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
   if (!st.active) return;
+  if (first_h) {  // deferred H: the launch before this one also wrote the H partials (workgroup-uniform branch)
+    __shared__ double sRedH[kBlock / 32][32];
+    __shared__ float sH[32];
+    __shared__ float sA[36];
+    __shared__ int sI[16];
+    reduce_partH(e, b, nblk, sRedH, sH);
+    if (e.sharded) {
+      if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sH[threadIdx.x];
+    } else {
+      expand_H(st, sH, sA);
+      if (threadIdx.x == 0) level_factor(st, sA, sI);
+      __syncthreads();  // st.LU / piv / luinfo are read back below
+    }
+  }
   {
     const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
     double s = 0.0;
@@ -510,13 +568,24 @@ __global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, in
 }
 
 // sharded mode: steps 9b-10 on the all-reduced b (red[b][21..26]); every rank does the same arithmetic
-__global__ void k_iter_finish(EngineDev e, int level) {
+__global__ void k_iter_finish(EngineDev e, int level, int first_h) {
   __shared__ float sLU[64][64];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= e.B) return;
   ProbState &st = e.st[b];
   if (!st.active) return;
   float *ws = sLU[threadIdx.x];
+  if (first_h) {  // deferred H: adopt the all-reduced H (red[b][0..20]) and factor it
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) {
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        const float v = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+        st.H[r * 6 + c] = v;
+        ws[r * 6 + c] = v;
+      }
+    for (int k = 0; k < kHUnique; ++k) e.red[(size_t)b * kRedStride + k] = 0.0f;
+    level_factor(st, ws, reinterpret_cast<int *>(ws) + 48);
+  }
   for (int k = 0; k < 36; ++k) ws[k] = st.LU[k];
   for (int k = 0; k < 12; ++k) reinterpret_cast<int *>(ws)[48 + k] = st.piv[k];
   reinterpret_cast<int *>(ws)[60] = st.luinfo[0];
@@ -587,10 +656,11 @@ struct PatchLoads {  // raw load results of one stage-2 step of kU patches (cons
   int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
 };
 
-template <bool PN, int kU, bool NT = true>
+template <bool PN, int kU, bool NT = true, bool WH = false>  // WH: also accumulate the 21 H sums (first launch of a level)
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartBStride];
+  __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
   const int b = blockIdx.y;
   const ProbState &st = e.st[b];
   if (!st.active) return;
@@ -618,6 +688,9 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   float acc[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+  float accH[WH ? kHUnique : 1];
+#pragma unroll
+  for (int j = 0; j < (WH ? kHUnique : 1); ++j) accH[j] = 0.0f;
 
   const int nchunks = (npts + cpw - 1) / cpw;
   for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
@@ -688,6 +761,20 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
           acc[3] += (gx * k0.z + gy * k1.w) * r;
           acc[4] += (gx * k0.w + gy * k2.x) * r;
           acc[5] += (gx * k1.x + gy * k2.y) * r;
+          if constexpr (WH) {  // H = sum sd_j sd_k over every stored patch, visible or stale (odometer.cpp:428-455)
+            float sd[6];
+            sd[0] = gx * k0.x;
+            sd[1] = gy * k1.y;
+            sd[2] = gx * k0.y + gy * k1.z;
+            sd[3] = gx * k0.z + gy * k1.w;
+            sd[4] = gx * k0.w + gy * k2.x;
+            sd[5] = gx * k1.x + gy * k2.y;
+            int jk = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c = a; c < 6; ++c) accH[jk++] += sd[a] * sd[c];
+          }
         }
       }
     };
@@ -713,21 +800,68 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
     e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
   }
+  if constexpr (WH) {
+#pragma unroll
+    for (int j = 0; j < kHUnique; ++j) {
+      const float v = wave_sum(accH[j]);
+      if (lane == 0) sWH[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kHUnique) {
+      const float v = (sWH[0][threadIdx.x] + sWH[1][threadIdx.x]) + (sWH[2][threadIdx.x] + sWH[3][threadIdx.x]);
+      e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
+    }
+  }
 }
 
 // steps 4-6 for 8x8 patches, same two-stage, software-pipelined form (reference patches + gradients, sd
 // coefficients, H partials). The patches T/Gx/Gy it stores are bit-exact (un-contracted blends); only the 21 H sums,
 // which are compared to tolerance, use FMA.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1))) *gconst_f32x4;
+
+// Packed taps: the setup kernel gathers the SAME 9x9 window from three planes. With the planes interleaved as one
+// {img, dx, dy, 0} texel per pixel a window row is 144 contiguous bytes (2 cache lines) instead of 3 x 36 bytes in
+// 3-6 lines, and two 16-byte loads per lane replace three 8-byte ones. Measured reason: the three separate gathers
+// pulled ~7 KB of lines per patch through an L1 that cannot hold the 20 waves' windows, and the kernel ran at the
+// L2's pace, not HBM's (ablations in profiles/r01_notes.md).
+struct TapLoads4 {
+  f32x4_t l, r, tl, tr;  // texels at (x-1, y), (x, y) and, for lanes 0-7, the row above
+};
+__device__ __forceinline__ TapLoads4 taps_issue4(gconst_f32x4 pack_at_base, int loff, int sw, int lane) {
+  TapLoads4 t;
+  t.l = pack_at_base[loff - 1];
+  t.r = pack_at_base[loff];
+  f32x4_t z = {0.0f, 0.0f, 0.0f, 0.0f};
+  t.tl = z;
+  t.tr = z;
+  if (lane < 8) {
+    t.tl = pack_at_base[loff - sw - 1];
+    t.tr = pack_at_base[loff - sw];
+  }
+  return t;
+}
+// same operand order as taps_blend (utilities.cpp:107), plane k of the texels
+__device__ __forceinline__ float taps_blend4(const TapLoads4 &t, int k, float w0, float w1, float w2, float w3, int lane) {
+  const float a = t.r[k], b = t.l[k];
+  const float cu = __shfl_up(a, 8, 64), du = __shfl_up(b, 8, 64);
+  const float c = lane < 8 ? t.tr[k] : cu, d = lane < 8 ? t.tl[k] : du;
+  return w0 * a + w1 * b + w2 * c + w3 * d;
+}
+
 template <int kU>
 struct RefLoads {
   TapLoads r[kU], x[kU], y[kU];
+  TapLoads4 p4[kU];
   float sgx[kU], sgy[kU];  // stale gradients of a patch that is out of the reference view at this level
   int rec[kU];
   int vis[kU];
 };
 
-template <bool PN, int kU, bool NT = true>
-__global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
+template <bool PN, int kU, bool NT = true, bool WH = true, bool PK = false>  // WH = false: H deferred; PK: packed planes
+__global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw, int dbg) {
+  // dbg (variant bits 9-11, ablation experiments only, results wrong on purpose): 1 no stores, 2 one plane's taps
+  // used for all three, 4 no tap loads at all
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartHStride];
   const int b = blockIdx.y;
@@ -742,6 +876,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   float *Gy = e.Gy + (size_t)b * M * 64;
   float *coefb = e.coef + (size_t)b * M * kCoefStride;
   gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
+  gconst_f32x4 ppack = (gconst_f32x4)pl.pack;
   const int sw = lc.sw;
 
   const int lane = threadIdx.x & 63;
@@ -750,9 +885,9 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   float *rec = sRec[wave];
   const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
 
-  float acc[kHUnique];
+  float acc[WH ? kHUnique : 1];
 #pragma unroll
-  for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
+  for (int j = 0; j < (WH ? kHUnique : 1); ++j) acc[j] = 0.0f;
 
   const int nchunks = (npts + cpw - 1) / cpw;
   for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
@@ -800,10 +935,21 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         const int base = rlane(base_v, jj);
         L.vis[u] = rlane(vis_v, jj);
         if (L.vis[u]) {  // wave-uniform
-          L.r[u] = taps_issue(pref + base, loff, sw, lane);
-          L.x[u] = taps_issue(pdx + base, loff, sw, lane);
-          L.y[u] = taps_issue(pdy + base, loff, sw, lane);
-        } else {
+          if constexpr (PK) {
+            L.p4[u] = taps_issue4(ppack + base, loff, sw, lane);
+          } else if (dbg & 4) {
+            L.r[u].ab = L.r[u].top = f32x2_a4{1.0f, 2.0f};
+            L.x[u] = L.y[u] = L.r[u];
+          } else {
+            L.r[u] = taps_issue(pref + base, loff, sw, lane);
+            if (dbg & 2) {
+              L.x[u] = L.y[u] = L.r[u];
+            } else {
+              L.x[u] = taps_issue(pdx + base, loff, sw, lane);
+              L.y[u] = taps_issue(pdy + base, loff, sw, lane);
+            }
+          }
+        } else if constexpr (WH) {
           const size_t po = (size_t)(i0 + jj) * 64;
           L.sgx[u] = (Gx + po)[lane];
           L.sgy[u] = (Gy + po)[lane];
@@ -818,12 +964,21 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
                      k2 = rec4[L.rec[u] * 4 + 3];
         float gx, gy;
         if (L.vis[u]) {
-          float t = taps_blend(L.r[u], w.x, w.y, w.z, w.w, lane);
+          float t;
+          if constexpr (PK) {
+            t = taps_blend4(L.p4[u], 0, w.x, w.y, w.z, w.w, lane);
+            gx = taps_blend4(L.p4[u], 1, w.x, w.y, w.z, w.w, lane);
+            gy = taps_blend4(L.p4[u], 2, w.x, w.y, w.z, w.w, lane);
+          } else {
+            t = taps_blend(L.r[u], w.x, w.y, w.z, w.w, lane);
+            gx = taps_blend(L.x[u], w.x, w.y, w.z, w.w, lane);
+            gy = taps_blend(L.y[u], w.x, w.y, w.z, w.w, lane);
+          }
           if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188
-          gx = taps_blend(L.x[u], w.x, w.y, w.z, w.w, lane);
-          gy = taps_blend(L.y[u], w.x, w.y, w.z, w.w, lane);
           const size_t po = (size_t)(i0 + L.rec[u]) * 64;
-          if constexpr (NT) {  // 400 MB written once per level: do not let them push the pyramid planes out of L2
+          if (dbg & 1) {
+            if (t + gx + gy == 1.2345e30f) T[po + lane] = t;  // keep the values alive
+          } else if constexpr (NT) {  // 400 MB written once per level: do not let them push the pyramid planes out of L2
             __builtin_nontemporal_store(t, T + po + lane);
             __builtin_nontemporal_store(gx, Gx + po + lane);
             __builtin_nontemporal_store(gy, Gy + po + lane);
@@ -832,11 +987,11 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
             (Gx + po)[lane] = gx;
             (Gy + po)[lane] = gy;
           }
-        } else {
+        } else if constexpr (WH) {
           gx = L.sgx[u];
           gy = L.sgy[u];
         }
-        {
+        if constexpr (WH) {
 #pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
           float sd[6];
           sd[0] = gx * k0.x;
@@ -865,15 +1020,17 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     __builtin_amdgcn_wave_barrier();
   }
 
+  if constexpr (WH) {
 #pragma unroll
-  for (int j = 0; j < kHUnique; ++j) {
-    const float v = wave_sum(acc[j]);
-    if (lane == 0) sW[wave][j] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kHUnique) {
-    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
-    e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
+    for (int j = 0; j < kHUnique; ++j) {
+      const float v = wave_sum(acc[j]);
+      if (lane == 0) sW[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kHUnique) {
+      const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+      e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
+    }
   }
 }
 
@@ -979,6 +1136,18 @@ void launch_pyr_down(const float *src, int pw, int ph, int psw, float *dst, int 
                      hipStream_t s) {
   hipLaunchKernelGGL(k_pyr_down, grid2d(w, h), dim3(kBlock), 0, s, src, pw, ph, psw, dst, w, h, pad, sw);
 }
+// interleave a finished level into {img, dx, dy, 0} texels (read by k_ref8's packed taps)
+__global__ __launch_bounds__(kBlock) void k_pyr_pack(const float *__restrict__ img, const float *__restrict__ dx,
+                                                     const float *__restrict__ dy, f32x4_t *pack, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    f32x4_t v = {img[i], dx[i], dy[i], 0.0f};
+    pack[i] = v;
+  }
+}
+void launch_pyr_pack(const float *img, const float *dx, const float *dy, float *pack, size_t n, hipStream_t s) {
+  const int g = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192);
+  hipLaunchKernelGGL(k_pyr_pack, dim3(g), dim3(kBlock), 0, s, img, dx, dy, reinterpret_cast<f32x4_t *>(pack), n);
+}
 void launch_pyr_finish(float *img, float *dx, float *dy, int w, int h, int pad, int sw, int sh, int getgrad,
                        hipStream_t s) {
   hipLaunchKernelGGL(k_pyr_finish, grid2d(sw, sh), dim3(kBlock), 0, s, img, dx, dy, w, h, pad, sw, sh, getgrad);
@@ -1001,41 +1170,73 @@ void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hi
   for (int l = 0; l < e.nlev && l < 16; ++l) ac.lc[l] = cams[l];
   hipLaunchKernelGGL(k_project_ref, dim3((maxpts + kBlock - 1) / kBlock, e.B), dim3(kBlock), 0, s, e, ac);
 }
+// Deferred H (P = 8 fast path, default): the setup kernel only gathers and stores the patches; the 21 H sums are
+// accumulated by the level's first iteration launch, which streams Gx, Gy and the coefficients anyway. Variant bit 8
+// (256) keeps H in the setup kernel (the previous form, kept for A/B and as a cross-check in the tests).
+bool defer_h(const EngineDev &e, int variant) { return e.P == 8 && !(variant & 2) && !(variant & 256); }
+
 // steps 4-6 of one level for every problem: accumulate kernel + per-problem tail
 void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
                       hipStream_t s) {
   const dim3 blk(kBlock);
   int nblk = gridx;
+  const bool dh = defer_h(e, variant);
   if (e.P == 8 && !(variant & 2)) {
     nblk = gridx8;
     const dim3 g8(gridx8, e.B);
     const int ku = (variant >> 6) & 3;  // experiments: patches per pipeline step of the setup kernel
-    if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_ref8<true, 1>), g8, blk, 0, s, e, lc, level, cpw);
+    const int dbg = (variant >> 9) & 7;
+    const bool pk = e.packed && !(variant & 4096);  // variant bit 12: three separate planes (A/B)
+    if (dh && pk) {
+      if (e.dopatchnorm)
+        hipLaunchKernelGGL((k_ref8<true, 1, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else if (ku == 2)
+        hipLaunchKernelGGL((k_ref8<false, 1, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else if (ku == 3)
+        hipLaunchKernelGGL((k_ref8<false, 4, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else  // default: two patches per pipeline step (measured: 1 -> 2 saves 50-120 us per level, 4 adds nothing)
+        hipLaunchKernelGGL((k_ref8<false, 2, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+    } else if (dh) {
+      if (e.dopatchnorm)
+        hipLaunchKernelGGL((k_ref8<true, 1, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else if (ku == 1)
+        hipLaunchKernelGGL((k_ref8<false, 2, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else if (ku == 3)
+        hipLaunchKernelGGL((k_ref8<false, 4, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else
+        hipLaunchKernelGGL((k_ref8<false, 1, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+    } else if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_ref8<true, 1>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
     else if (ku == 1)
-      hipLaunchKernelGGL((k_ref8<false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_ref8<false, 2>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
     else if (ku == 2)
-      hipLaunchKernelGGL((k_ref8<false, 1, false>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal stores
+      hipLaunchKernelGGL((k_ref8<false, 1, false>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);  // A/B: temporal stores
     else
-      hipLaunchKernelGGL((k_ref8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_ref8<false, 1>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
   } else if (e.P == 4)
     hipLaunchKernelGGL(k_ref_level<4>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
     hipLaunchKernelGGL(k_ref_level<0>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
-  hipLaunchKernelGGL(k_level_tail, dim3(e.B), blk, 0, s, e, nblk);
+  hipLaunchKernelGGL(k_level_tail, dim3(e.B), blk, 0, s, e, nblk, dh ? 1 : 0);
 }
-void launch_level_finish(const EngineDev &e, hipStream_t s) {
-  hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e);
+void launch_level_finish(const EngineDev &e, int variant, hipStream_t s) {
+  hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e, defer_h(e, variant) ? 1 : 0);
 }
 // steps 7-9a of one Gauss-Newton iteration for every problem (the accumulate kernel) ...
+// first: the level's first iteration (with deferred H it also accumulates the H partials)
 void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
-                      hipStream_t s) {
+                      int first, hipStream_t s) {
   const dim3 blk(kBlock);
   if (e.P == 8 && !(variant & 2)) {
     const dim3 g8(gridx8, e.B);
     // patches per pipeline step: 4 measured best (profiles/r01_notes.md); variant bits 4-5 select others for A/B
     const int ku = (variant >> 4) & 3;
-    if (e.dopatchnorm)
+    if (first && defer_h(e, variant)) {
+      if (e.dopatchnorm)
+        hipLaunchKernelGGL((k_iter8<true, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
+      else
+        hipLaunchKernelGGL((k_iter8<false, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
+    } else if (e.dopatchnorm)
       hipLaunchKernelGGL((k_iter8<true, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
       hipLaunchKernelGGL((k_iter8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
@@ -1051,17 +1252,18 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
     hipLaunchKernelGGL((k_iter<0>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
 }
 // ... and steps 9b-10 (one workgroup per problem)
-void launch_iter_tail(const EngineDev &e, int level, int gridx, int variant, int gridx8, hipStream_t s) {
+void launch_iter_tail(const EngineDev &e, int level, int gridx, int variant, int gridx8, int first, hipStream_t s) {
   const int nblk = (e.P == 8 && !(variant & 2)) ? gridx8 : gridx;
-  hipLaunchKernelGGL(k_iter_tail, dim3(e.B), dim3(kBlock), 0, s, e, level, nblk);
+  hipLaunchKernelGGL(k_iter_tail, dim3(e.B), dim3(kBlock), 0, s, e, level, nblk, (first && defer_h(e, variant)) ? 1 : 0);
 }
 void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
-                 hipStream_t s) {
-  launch_iter_main(e, lc, level, gridx, variant, cpw, gridx8, s);
-  launch_iter_tail(e, level, gridx, variant, gridx8, s);
+                 int first, hipStream_t s) {
+  launch_iter_main(e, lc, level, gridx, variant, cpw, gridx8, first, s);
+  launch_iter_tail(e, level, gridx, variant, gridx8, first, s);
 }
-void launch_iter_finish(const EngineDev &e, int level, hipStream_t s) {
-  hipLaunchKernelGGL(k_iter_finish, dim3((e.B + 63) / 64), dim3(64), 0, s, e, level);
+void launch_iter_finish(const EngineDev &e, int level, int variant, int first, hipStream_t s) {
+  hipLaunchKernelGGL(k_iter_finish, dim3((e.B + 63) / 64), dim3(64), 0, s, e, level,
+                     (first && defer_h(e, variant)) ? 1 : 0);
 }
 
 }  // namespace ictr

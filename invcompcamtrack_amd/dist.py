@@ -5,6 +5,8 @@ coupling between points is the sum into one 6x6 / 6x1 system -- ComputeHessian (
 step 9a (odometer.cpp:399-404) -- so every rank owns a contiguous block of points (SoA slices), frames are
 replicated, and per problem the ranks exchange
     21 floats of H once per pyramid level,   6 floats of b once per Gauss-Newton iteration
+(on the 8x8 fast path the H of a level is accumulated by its first iteration launch and travels in the same
+27-float message as that iteration's b: one collective per iteration, none per level)
 with ``torch.distributed.all_reduce(SUM)`` (backend "nccl" = RCCL over xGMI). Every rank then runs the same
 solve / pose update on identical bits, so no broadcast is needed and the early-exit test stays in lockstep.
 Nothing is read back to the host inside the loop: the accumulate kernels, the collective and the finish
@@ -51,10 +53,12 @@ def run_sharded_levels(engine, op, allreduce):
     begin / level_accumulate / level_finish / iter_accumulate / iter_finish (a TrackBatch, or a test double);
     ``allreduce()`` sums the engine's reduction buffer over all ranks."""
     engine.begin()
+    level_ar = getattr(engine, "needs_level_allreduce", True)
     for sl in range(op.lv_f, op.lv_l - 1, -1):
-        engine.level_accumulate(sl)   # steps 4-6 on the local points -> local H
-        allreduce()
-        engine.level_finish(sl)       # adopt the global H, reset the iteration state
+        engine.level_accumulate(sl)   # steps 4-6 on the local points -> local H (8x8 fast path: H comes with the
+        if level_ar:                  # first iteration's b instead, 27 floats in one message, no level collective)
+            allreduce()
+        engine.level_finish(sl)       # adopt the global H (if it is there yet), reset the iteration state
         for _ in range(op.maxiter):   # converged problems skip their work on the device (same decision on every rank)
             engine.iter_accumulate(sl)  # steps 7-9a on the local points -> local b
             allreduce()
@@ -68,11 +72,13 @@ def sharded_program(engine, op, allreduce_async):
     collective latency is hidden behind compute instead of adding to every Gauss-Newton iteration.
     ``allreduce_async()`` starts the reduction of the engine's buffer and returns an object with ``wait()``."""
     engine.begin()
+    level_ar = getattr(engine, "needs_level_allreduce", True)
     for sl in range(op.lv_f, op.lv_l - 1, -1):
         engine.level_accumulate(sl)
-        h = allreduce_async()
-        yield
-        h.wait()
+        if level_ar:
+            h = allreduce_async()
+            yield
+            h.wait()
         engine.level_finish(sl)
         for _ in range(op.maxiter):
             engine.iter_accumulate(sl)

@@ -404,6 +404,12 @@ class TrackBatch:
     def reduction_buffer_ptr(self):
         return _lib.load().ictr_batch_reduction_buffer(self._h)
 
+    @property
+    def needs_level_allreduce(self):
+        """False on the 8x8 fast path: H is accumulated by the level's first iteration launch and travels with
+        that iteration's b, so the level phase needs no collective of its own."""
+        return bool(_lib.load().ictr_batch_level_allreduce_needed(self._h))
+
     def begin(self): check(_lib.load().ictr_batch_begin(self._h))
     def level_accumulate(self, level): check(_lib.load().ictr_batch_level_accumulate(self._h, level))
     def level_finish(self, level): check(_lib.load().ictr_batch_level_finish(self._h, level))

@@ -173,18 +173,23 @@ def test_fast_path_equals_generic_path(oracle):
     Same arithmetic per element, different summation order: identical setup buffers, poses to float noise."""
     sc = scene(256, 224, 300, seed=9, margin=12.0)
     res = []
-    for variant in (0, 2):
+    # variant 256: fast path with H accumulated by the setup kernel instead of by the first iteration launch
+    for variant in (0, 2, 256):
         for dpn in (0, 1):
             pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, dpn, variant=variant)
             pr.set_points()
             pr.set_pose()
             po, pg = pr.track()
             assert np.abs(po - pg).max() <= POSE_TOL
-            res.append((pg, pr.odo.read_buffer(0, 64 * 300), pr.odo.read_buffer(1, 64 * 300), pr.odo.read_buffer(7, 16 * 300)))
+            res.append((pg, pr.odo.read_buffer(0, 64 * 300), pr.odo.read_buffer(1, 64 * 300),
+                        pr.odo.read_buffer(7, 16 * 300), pr.odo.trace()))
     for k in (0, 1):
-        fast, gen = res[k], res[2 + k]
-        assert np.abs(fast[0] - gen[0]).max() <= 2e-6
-        assert np.array_equal(fast[1], gen[1]) and np.array_equal(fast[2], gen[2]) and np.array_equal(fast[3], gen[3])
+        fast = res[k]
+        for other in (res[2 + k], res[4 + k]):
+            assert np.abs(fast[0] - other[0]).max() <= 2e-6
+            assert np.array_equal(fast[1], other[1]) and np.array_equal(fast[2], other[2]) and np.array_equal(fast[3], other[3])
+            assert len(fast[4]) == len(other[4])
+            assert rel(fast[4][0]["H"], other[4][0]["H"]) <= SUM_TOL      # H of the first level, whoever summed it
 
 
 def test_points_out_of_view_and_stale_state_across_frames(oracle):
@@ -332,7 +337,7 @@ def test_sharded_phases_equal_fused_run(oracle):
 
     class TwoShards:
         def __init__(self):
-            self.parts, self.red = [], []
+            self.parts, self.red, self.n_allreduce = [], [], 0
             for lo, hi in shard_slices(301, 2):
                 b = ic.TrackBatch(cam, op, 1)
                 b.enable_sharding(True)
@@ -343,6 +348,10 @@ def test_sharded_phases_equal_fused_run(oracle):
                 self.parts.append(b)
                 self.red.append(r)
 
+        @property
+        def needs_level_allreduce(self):
+            return self.parts[0].needs_level_allreduce
+
         def __getattr__(self, name):
             def call(*a):
                 for b in self.parts:
@@ -350,6 +359,7 @@ def test_sharded_phases_equal_fused_run(oracle):
             return call
 
         def allreduce(self):
+            self.n_allreduce += 1
             torch.cuda.synchronize()
             s = self.red[0] + self.red[1]
             for r in self.red:
@@ -362,6 +372,7 @@ def test_sharded_phases_equal_fused_run(oracle):
     assert np.array_equal(p0, p1)                 # both "ranks" hold the same pose bits
     assert np.abs(p0 - p_full).max() <= 2e-6
     assert list(eng.parts[0].iterations()) == list(full.iterations())
+    assert not eng.needs_level_allreduce and eng.n_allreduce == 3 * 6   # 8x8 fast path: H rides with the first b
 
 
 @pytest.mark.parametrize("wh", [(1920, 1080), (1280, 720)])

@@ -58,7 +58,42 @@ __global__ __launch_bounds__(256) void k_stream3_chunk(const float* __restrict__
   if (acc == 123.456f) out[wave] = acc;
 }
 
-int main() {
+// store-only, copy, and "read 1, write 3" (the shape of k_ref8: one plane window in, three patch streams out)
+template <int W, bool NT>
+__global__ __launch_bounds__(256) void k_write(float* dst, size_t n, float v) {
+  typedef float vec __attribute__((ext_vector_type(W)));
+  vec* d = reinterpret_cast<vec*>(dst);
+  const size_t nv = n / W;
+  vec x;
+  for (int k = 0; k < W; ++k) x[k] = v;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    if (NT) __builtin_nontemporal_store(x, d + i); else d[i] = x;
+  }
+}
+template <int W, bool NT>
+__global__ __launch_bounds__(256) void k_copy(const float* __restrict__ src, float* dst, size_t n) {
+  typedef float vec __attribute__((ext_vector_type(W)));
+  const vec* s = reinterpret_cast<const vec*>(src);
+  vec* d = reinterpret_cast<vec*>(dst);
+  const size_t nv = n / W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    const vec x = NT ? __builtin_nontemporal_load(s + i) : s[i];
+    if (NT) __builtin_nontemporal_store(x, d + i); else d[i] = x;
+  }
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void k_r1w3(const float* __restrict__ src, float* d0, float* d1, float* d2, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float x = src[i];
+    if (NT) {
+      __builtin_nontemporal_store(x, d0 + i); __builtin_nontemporal_store(x + 1.f, d1 + i); __builtin_nontemporal_store(x + 2.f, d2 + i);
+    } else {
+      d0[i] = x; d1[i] = x + 1.f; d2[i] = x + 2.f;
+    }
+  }
+}
+
+int main(int argc, char** argv) {
   const size_t n = (size_t)128 << 20;  // 128 Mi floats = 512 MB per array
   float *a, *b, *c, *out;
   CHK(hipMalloc(&a, n * 4)); CHK(hipMalloc(&b, n * 4)); CHK(hipMalloc(&c, n * 4)); CHK(hipMalloc(&out, 64 << 20));
@@ -72,6 +107,21 @@ int main() {
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-44s %8.1f us  %7.2f TB/s\n", name, ms / 5 * 1e3, bytes / (ms / 5 * 1e-3) / 1e12);
   };
+  if (argc > 1) {  // write-side tests only
+    float* d; CHK(hipMalloc(&d, n * 4));
+    for (int g : {4096, 16384}) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "write W=1 temporal grid %d", g); time([&] { k_write<1, false><<<g, 256>>>(a, n, 1.f); }, n * 4.0, nm);
+      snprintf(nm, sizeof nm, "write W=1 NT grid %d", g);       time([&] { k_write<1, true><<<g, 256>>>(a, n, 1.f); }, n * 4.0, nm);
+      snprintf(nm, sizeof nm, "write W=4 temporal grid %d", g); time([&] { k_write<4, false><<<g, 256>>>(a, n, 1.f); }, n * 4.0, nm);
+      snprintf(nm, sizeof nm, "write W=4 NT grid %d", g);       time([&] { k_write<4, true><<<g, 256>>>(a, n, 1.f); }, n * 4.0, nm);
+      snprintf(nm, sizeof nm, "copy W=1 temporal grid %d (r+w bytes)", g); time([&] { k_copy<1, false><<<g, 256>>>(a, b, n); }, n * 8.0, nm);
+      snprintf(nm, sizeof nm, "copy W=4 NT grid %d (r+w bytes)", g);       time([&] { k_copy<4, true><<<g, 256>>>(a, b, n); }, n * 8.0, nm);
+      snprintf(nm, sizeof nm, "read1 write3 temporal grid %d (r+w bytes)", g); time([&] { k_r1w3<false><<<g, 256>>>(a, b, c, d, n); }, n * 16.0, nm);
+      snprintf(nm, sizeof nm, "read1 write3 NT grid %d (r+w bytes)", g);       time([&] { k_r1w3<true><<<g, 256>>>(a, b, c, d, n); }, n * 16.0, nm);
+    }
+    return 0;
+  }
   const int grids[] = {2048, 4096, 8192};
   for (int g : grids) {
     char nm[128];
