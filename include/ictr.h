@@ -202,6 +202,8 @@ int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters);
 /* ms_kernel[l]: summed duration of the level's maxiter accumulate-kernel launches ALONE (events around each launch,
  * excluding the tail kernels and the gaps) -- the figure comparable with rocprofv3 --kernel-trace --stats */
 int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel);
+/* ms per level of the level's FIRST accumulate launch alone (8x8 fast path: the instantiation that also sums H) */
+int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first);
 
 /* ---- distributed (points sharded over ranks): split phases so the caller can all-reduce ----
  * The normal-equation block lives in a caller-visible device buffer: per problem 21 floats of H

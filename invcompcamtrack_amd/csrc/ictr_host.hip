@@ -1027,6 +1027,19 @@ extern "C" int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel) {
   }
   return ICTR_OK;
 }
+// the first accumulate launch of each level alone (on the 8x8 fast path it is a different kernel instantiation: it
+// also accumulates the 21 H sums), so that callers can report the regular iteration kernel separately
+extern "C" int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first) {
+  if (!b || !ms_first) return fail(ICTR_ERR_INVALID, "get_first_iter_times: NULL argument");
+  if (b->evk.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
+  if (int rc = batch_wait(b)) return rc;
+  for (int l = 0; l < b->nlev; ++l) {
+    ms_first[l] = 0.0f;
+    if (!b->ev_used[l] || b->op->maxiter < 1) continue;
+    HIPCHK(hipEventElapsedTime(&ms_first[l], b->evk[2 * (l * b->evk_iters)], b->evk[2 * (l * b->evk_iters) + 1]));
+  }
+  return ICTR_OK;
+}
 extern "C" int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   b->d_red = dev_ptr ? dev_ptr : b->d_red_own;

@@ -394,6 +394,12 @@ class TrackBatch:
         check(_lib.load().ictr_batch_get_kernel_times(self._h, fp(a)))
         return a
 
+    def first_iter_times(self):
+        """ms per level of the first accumulate launch alone (it also sums H on the 8x8 fast path)."""
+        a = np.zeros(self.op.lv_f + 1, np.float32)
+        check(_lib.load().ictr_batch_get_first_iter_times(self._h, fp(a)))
+        return a
+
     def set_reduction_buffer(self, dev_ptr):
         check(_lib.load().ictr_batch_set_reduction_buffer(self._h, C.c_void_p(dev_ptr or 0)))
 
