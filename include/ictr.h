@@ -169,6 +169,7 @@ int ictr_odometer_read_buffer(ictr_odometer *odo, int which, float *host_out, in
 int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double *varval);
 /* kernel variant for A/B runs: bit0 = stage the current-frame window through LDS */
 int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
+int ictr_odometer_set_robust(ictr_odometer *odo, int flags, float huber_k); /* see ictr_batch_set_robust */
 
 /* ------------------------------------------------------------------ batched engine (B independent problems) */
 typedef struct ictr_batch ictr_batch;
@@ -192,6 +193,16 @@ int ictr_batch_get_poses(ictr_batch *b, double *p_out);
 int ictr_batch_get_iterations(ictr_batch *b, int *iters);
 int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out /* 2*M */);
 int ictr_batch_set_variant(ictr_batch *b, int variant);
+/* Behaviour-changing robustness options, all OFF by default (the default reproduces the reference, quirks included).
+ * flags: ICTR_ROBUST_CLEAN  points outside the reference view at a level contribute nothing (the reference reuses
+ *                           their stale patches and sd coefficients, odometer.cpp:304);
+ *        ICTR_ROBUST_COMPOSE left-compositional update G <- exp(dp) G instead of p += dp (pose.cpp:118-123);
+ *        ICTR_ROBUST_HUBER  residuals weighted min(1, huber_k / |r|) in J^T r (H stays the precomputed one).
+ * With any flag set the 8x8 fast path is bypassed (any-size kernels). Oracle: oracle/np_oracle.py (same options). */
+#define ICTR_ROBUST_CLEAN 1
+#define ICTR_ROBUST_COMPOSE 2
+#define ICTR_ROBUST_HUBER 4
+int ictr_batch_set_robust(ictr_batch *b, int flags, float huber_k);
 /* inspection, like ictr_odometer_read_buffer; additionally which = 8: the problem's device state as floats */
 int ictr_batch_read_buffer(ictr_batch *b, int64_t problem, int which, float *host_out, int64_t count);
 /* HIP-event timing on the batch's own stream: when enabled, ictr_batch_track_async brackets, per level, the

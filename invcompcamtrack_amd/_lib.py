@@ -97,6 +97,7 @@ SIGNATURES = {
     "ictr_odometer_read_buffer": (C.c_int, [VP, C.c_int, FP, I64]),
     "ictr_odometer_get_norm": (C.c_int, [VP, DP, DP]),
     "ictr_odometer_set_variant": (C.c_int, [VP, C.c_int]),
+    "ictr_odometer_set_robust": (C.c_int, [VP, C.c_int, C.c_float]),
     "ictr_batch_create": (C.c_int, [C.POINTER(VP), VP, C.POINTER(OptParam), I64]),
     "ictr_batch_destroy": (None, [VP]),
     "ictr_batch_set_stream": (C.c_int, [VP, VP]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "ictr_batch_get_iterations": (C.c_int, [VP, IP]),
     "ictr_batch_get2dpoints": (C.c_int, [VP, I64, FP]),
     "ictr_batch_set_variant": (C.c_int, [VP, C.c_int]),
+    "ictr_batch_set_robust": (C.c_int, [VP, C.c_int, C.c_float]),
     "ictr_batch_read_buffer": (C.c_int, [VP, I64, C.c_int, FP, I64]),
     "ictr_batch_set_timing": (C.c_int, [VP, C.c_int]),
     "ictr_batch_get_level_times": (C.c_int, [VP, FP, FP]),

@@ -63,6 +63,12 @@ struct EngineDev {
   int dopatchnorm;
   int sharded;  // 1: accumulate kernels stop after writing rank-local sums to red[]
   int packed;   // 1: every problem's reference pyramid carries the interleaved {img, dx, dy, 0} planes
+  // behaviour-changing options, all off by default; any of them routes P = 8 through the
+  // any-size kernels. ICTR_ROBUST_CLEAN: a point outside the reference view at a level contributes nothing (its
+  // stale patches / gradients are zeroed instead of reused, cf. odometer.cpp:304); ICTR_ROBUST_COMPOSE: G <- exp(dp) G
+  // instead of p += dp (pose.cpp:118-123); ICTR_ROBUST_HUBER: residuals weighted min(1, k / |r|) in J^T r.
+  int robust;
+  float huber_k;
   float *pt3d;      // [B][3M]  X..Y..Z..
   float *pt3d_ref;  // [B][3M]  camera-frame points at the reference pose
   float *pt2d;      // [B][nlev][2M]

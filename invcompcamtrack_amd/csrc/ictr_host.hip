@@ -550,6 +550,8 @@ struct ictr_batch {
   int B = 0, M = 0, n = 0, nlev = 0, P = 0;
   hipStream_t stream = nullptr;
   int variant = 0;
+  int robust = 0;        // ICTR_ROBUST_* (off by default)
+  float huber_k = 0.0f;
   int sharded = 0;
   int gridx = 1;
   int cpw = 64, gridx8 = 1;  // P=8 fast path: points per wave chunk, workgroups per problem
@@ -603,6 +605,8 @@ static void batch_free(ictr_batch *b) {
   delete b;
 }
 
+// kernel-selection bits as the launchers see them: any robustness option routes P = 8 through the any-size kernels
+static int engine_variant(const ictr_batch *b) { return b->variant | (b->robust ? 2 : 0); }
 static EngineDev engine_dev(const ictr_batch *b) {
   EngineDev e;
   e.B = b->B;
@@ -617,6 +621,8 @@ static EngineDev engine_dev(const ictr_batch *b) {
   e.dopatchnorm = b->op->dopatchnorm ? 1 : 0;
   e.sharded = b->sharded;
   e.packed = b->packed;
+  e.robust = b->robust;
+  e.huber_k = b->huber_k;
   e.pt3d = b->d_pt3d;
   e.pt3d_ref = b->d_pt3d_ref;
   e.pt2d = b->d_pt2d;
@@ -708,6 +714,16 @@ extern "C" void ictr_batch_destroy(ictr_batch *b) { batch_free(b); }
 extern "C" int ictr_batch_set_stream(ictr_batch *b, void *hip_stream) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   b->stream = (hipStream_t)hip_stream;
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_set_robust(ictr_batch *b, int flags, float huber_k) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (flags & ~(ICTR_ROBUST_CLEAN | ICTR_ROBUST_COMPOSE | ICTR_ROBUST_HUBER))
+    return fail(ICTR_ERR_INVALID, "set_robust: unknown flag bits 0x%x", flags);
+  if ((flags & ICTR_ROBUST_HUBER) && !(huber_k > 0.0f))
+    return fail(ICTR_ERR_INVALID, "set_robust: the Huber threshold must be positive");
+  b->robust = flags;
+  b->huber_k = huber_k;
   return ICTR_OK;
 }
 extern "C" int ictr_batch_set_variant(ictr_batch *b, int variant) {
@@ -899,19 +915,19 @@ static int level_ok(ictr_batch *b, int level) {
 // 0 (P = 8 fast path, deferred H): H travels with the first iteration's b, the level phase needs no collective
 extern "C" int ictr_batch_level_allreduce_needed(ictr_batch *b) {
   if (!b) return 1;
-  return defer_h(engine_dev(b), b->variant) ? 0 : 1;
+  return defer_h(engine_dev(b), engine_variant(b)) ? 0 : 1;
 }
 extern "C" int ictr_batch_level_accumulate(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
   b->phase_it = 0;
-  launch_ref_level(engine_dev(b), level_cam(b->cam, level), level, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+  launch_ref_level(engine_dev(b), level_cam(b->cam, level), level, b->gridx, engine_variant(b), b->cpw, b->gridx8, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
 extern "C" int ictr_batch_level_finish(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
   b->phase_it = 0;
-  if (b->sharded) launch_level_finish(engine_dev(b), b->variant, b->stream);
+  if (b->sharded) launch_level_finish(engine_dev(b), engine_variant(b), b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -923,19 +939,19 @@ extern "C" int ictr_batch_iter_accumulate(ictr_batch *b, int level) {
   const LevelCam lc = level_cam(b->cam, level);
   if (tk) HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it)], b->stream));
   const int first = b->phase_it == 0;
-  launch_iter_main(e, lc, level, b->gridx, b->variant, b->cpw, b->gridx8, first, b->stream);
+  launch_iter_main(e, lc, level, b->gridx, engine_variant(b), b->cpw, b->gridx8, first, b->stream);
   if (tk) {
     HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it) + 1], b->stream));
     if (b->phase_it + 1 == std::min(b->op->maxiter, b->evk_iters)) b->ev_used[level] = 2;  // kernel events complete
   }
   b->phase_it++;
-  launch_iter_tail(e, level, b->gridx, b->variant, b->gridx8, first, b->stream);
+  launch_iter_tail(e, level, b->gridx, engine_variant(b), b->gridx8, first, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
 extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
   if (int rc = level_ok(b, level)) return rc;
-  if (b->sharded) launch_iter_finish(engine_dev(b), level, b->variant, b->phase_it == 1, b->stream);
+  if (b->sharded) launch_iter_finish(engine_dev(b), level, engine_variant(b), b->phase_it == 1, b->stream);
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }
@@ -950,13 +966,13 @@ static int enqueue_levels(ictr_batch *b) {
   for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
     const LevelCam lc = level_cam(b->cam, sl);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], b->stream));
-    launch_ref_level(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, b->stream);
+    launch_ref_level(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, b->stream);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], b->stream));
     for (int it = 0; it < mi; ++it) {
       if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it)], b->stream));
-      launch_iter_main(e, lc, sl, b->gridx, b->variant, b->cpw, b->gridx8, it == 0, b->stream);
+      launch_iter_main(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, it == 0, b->stream);
       if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it) + 1], b->stream));
-      launch_iter_tail(e, sl, b->gridx, b->variant, b->gridx8, it == 0, b->stream);
+      launch_iter_tail(e, sl, b->gridx, engine_variant(b), b->gridx8, it == 0, b->stream);
     }
     if (b->timing) {
       HIPCHK(hipEventRecord(b->ev[3 * sl + 2], b->stream));
@@ -1113,6 +1129,10 @@ extern "C" void ictr_odometer_destroy(ictr_odometer *o) {
 extern "C" int ictr_odometer_set_stream(ictr_odometer *o, void *s) {
   if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
   return ictr_batch_set_stream(o->b, s);
+}
+extern "C" int ictr_odometer_set_robust(ictr_odometer *o, int flags, float huber_k) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  return ictr_batch_set_robust(o->b, flags, huber_k);
 }
 extern "C" int ictr_odometer_set_variant(ictr_odometer *o, int v) {
   if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");

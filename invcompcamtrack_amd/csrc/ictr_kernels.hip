@@ -126,13 +126,32 @@ __device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, i
   const int *iws = reinterpret_cast<const int *>(ws + 48);
   lu_apply_ws<6>(ws, iws, iws + 12, ws + 36, dp, ws + 42);
   float p[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    st.dp[k] = dp[k];
-    p[k] = st.p[k] + dp[k];  // pose.cpp:118-123 additive update
-    st.p[k] = p[k];
-  }
   float G[12];
+  if (e.robust & ICTR_ROBUST_COMPOSE) {  // option: left-compositional update G <- exp(dp) G, p = log(G)
+    float D[12], Go[12];
+    se3_exp<float>(D, dp);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Go[k] = st.G[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        G[r * 4 + c] = D[r * 4 + 0] * Go[c] + D[r * 4 + 1] * Go[4 + c] + D[r * 4 + 2] * Go[8 + c] + (c == 3 ? D[r * 4 + 3] : 0.0f);
+    }
+    se3_log<float>(p, G);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      st.dp[k] = dp[k];
+      st.p[k] = p[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      st.dp[k] = dp[k];
+      p[k] = st.p[k] + dp[k];  // pose.cpp:118-123 additive update
+      st.p[k] = p[k];
+    }
+  }
   se3_exp<float>(G, p);
 #pragma unroll
   for (int k = 0; k < 12; ++k) st.G[k] = G[k];
@@ -293,8 +312,13 @@ __global__ __launch_bounds__(kBlock) void k_ref_level(EngineDev e, LevelCam lc, 
         Gx[o] = gx;
         Gy[o] = gy;
       } else if (valid) {
-        gx = Gx[o];
-        gy = Gy[o];
+        if (e.robust & ICTR_ROBUST_CLEAN) {  // option: no stale contributions, neither to H nor (through sd) to b
+          Gx[o] = 0.0f;
+          Gy[o] = 0.0f;
+        } else {
+          gx = Gx[o];
+          gy = Gy[o];
+        }
       }
       float sd[6];
       sd_values(gx, gy, cx, cy, sd);
@@ -496,7 +520,11 @@ __global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int l
         const size_t o = (size_t)i * n + q;
         float inew = tap4(cur, base + (q / P) * lc.sw + (q % P), lc.sw, tp);
         if (e.dopatchnorm) inew -= mean;
-        const float r = T[o] - inew;  // pdiff (odometer.cpp:381)
+        float r = T[o] - inew;  // pdiff (odometer.cpp:381)
+        if (e.robust & ICTR_ROBUST_HUBER) {
+          const float ar = fabsf(r);
+          if (ar > e.huber_k) r *= e.huber_k / ar;
+        }
         float sd[6];
         sd_values(Gx[o], Gy[o], cx, cy, sd);
 #pragma unroll
@@ -1174,6 +1202,7 @@ void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hi
 // accumulated by the level's first iteration launch, which streams Gx, Gy and the coefficients anyway. Variant bit 8
 // (256) keeps H in the setup kernel (the previous form, kept for A/B and as a cross-check in the tests).
 bool defer_h(const EngineDev &e, int variant) { return e.P == 8 && !(variant & 2) && !(variant & 256); }
+// (the host sets variant bit 1 whenever a robustness option is on, see engine_variant in ictr_host.hip)
 
 // steps 4-6 of one level for every problem: accumulate kernel + per-problem tail
 void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,

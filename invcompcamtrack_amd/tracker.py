@@ -246,6 +246,11 @@ class OdometerClass:
     def set_variant(self, variant):
         check(_lib.load().ictr_odometer_set_variant(self._h, int(variant)))
 
+    def set_robust(self, clean_invisible=False, compositional=False, huber_k=0.0):
+        """Behaviour-changing options, off by default (see ictr_batch_set_robust)."""
+        flags = (1 if clean_invisible else 0) | (2 if compositional else 0) | (4 if huber_k > 0 else 0)
+        check(_lib.load().ictr_odometer_set_robust(self._h, flags, float(huber_k)))
+
     def Set3Dpoints(self, pt_in, nopoints_in=None):
         """pt_in: float64, C-contiguous, SoA X..Y..Z.. (shape (3,n) or flat). Mutated in place when
         op.donorm, exactly like the reference (odometer.cpp:207-212)."""
@@ -329,6 +334,11 @@ class TrackBatch:
 
     def set_variant(self, variant):
         check(_lib.load().ictr_batch_set_variant(self._h, int(variant)))
+
+    def set_robust(self, clean_invisible=False, compositional=False, huber_k=0.0):
+        """Behaviour-changing options, off by default (see ictr_batch_set_robust)."""
+        flags = (1 if clean_invisible else 0) | (2 if compositional else 0) | (4 if huber_k > 0 else 0)
+        check(_lib.load().ictr_batch_set_robust(self._h, flags, float(huber_k)))
 
     def Set3Dpoints(self, problem, pt_in, nopoints_in=None):
         if not (isinstance(pt_in, np.ndarray) and pt_in.dtype == np.float64 and pt_in.flags.c_contiguous):

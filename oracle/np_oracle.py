@@ -88,10 +88,12 @@ def sd_coefs(X, Y, Z, fx, fy):
     return cx, cy
 
 
-def track(pts3d, p_in, pyr_ref, pyr_new, cam, lv_f, lv_l, psz, maxiter, solve):
+def track(pts3d, p_in, pyr_ref, pyr_new, cam, lv_f, lv_l, psz, maxiter, solve, compose=None, huber_k=0.0):
     """No-normalisation TrackPose (odometer.cpp:257-426) for points that stay in view.
     pyr_*: object with .img/.dx/.dy lists of padded planes; cam(which, level) -> float; solve(H,b) -> dp.
-    Returns (p float32[6], trace list of dict(level, iter, H, b, dp))."""
+    Returns (p float32[6], trace list of dict(level, iter, H, b, dp)).
+    Options of the build's robustness extension (not reference behaviour): compose(p, dp) -> p_new replaces the
+    additive update (the test passes log(exp(dp) exp(p))); huber_k > 0 weights residuals min(1, k/|r|) in b."""
     X, Y, Z = (pts3d[k].astype(f32) for k in range(3))
     p = np.asarray(p_in, np.float64).astype(f32)
     G0 = exp_se3(p)
@@ -114,8 +116,11 @@ def track(pts3d, p_in, pyr_ref, pyr_new, cam, lv_f, lv_l, psz, maxiter, solve):
             nx, ny, _, _, _ = project(G, X, Y, Z, fx, fy, cx_, cy_)
             I = patches(pyr_new.img[sl], nx, ny, psz)
             r = T - I
+            if huber_k > 0:
+                ar = np.abs(r)
+                r = np.where(ar > f32(huber_k), r * (f32(huber_k) / np.where(ar > 0, ar, f32(1))), r).astype(f32)
             b = (sd * r[:, None]).reshape(len(X), 6, -1).astype(np.float64).sum((0, 2)).astype(f32)
             dp = solve(H, b)
-            p = p + dp
+            p = (p + dp) if compose is None else np.asarray(compose(p, dp), f32)
             trace.append(dict(level=sl, iter=it, H=H, b=b, dp=dp, p=p.copy()))
     return p, trace
