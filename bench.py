@@ -130,7 +130,16 @@ def cpu_baseline(args, scene, n_pts):
         runs += 1
         if time.perf_counter() > t_end or runs >= 1000:
             break
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": pix_per_run * runs / t_used / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "cpu_model": cpu_model, "host_cores": os.cpu_count(),
             "gn_iters_per_s": args.levels * args.maxiter * runs / t_used,
             "sample": f"{runs} full trackings of one {args.width}x{args.height} frame pair ({n_pts} points, "
                       f"{args.levels} levels x {args.maxiter} iterations), {t_used:.1f} s; oracle/libictr_oracle.so "
@@ -169,6 +178,10 @@ def main():
     from invcompcamtrack_amd import _lib
     _lib.check(_lib.load().ictr_set_device(local_rank if world > 1 else 0))
 
+    # yardstick: what a plain streaming read reaches on this box (2 GiB, far beyond the Infinity Cache)
+    import ctypes
+    stream_gbps = ctypes.c_double(0.0)
+    _lib.check(_lib.load().ictr_stream_read_bandwidth(2 << 30, 5, ctypes.byref(stream_gbps)))
     inp = build_inputs(args, rank, world)
     op, pyrs, scenes = inp["op"], inp["pyrs"], inp["scenes"]
     B, P, n_pts = args.batch, args.psz, inp["n_pts"]
@@ -362,6 +375,8 @@ def main():
                                "kernel": "k_iter8 (GN iteration: steps 7-9a), mean over the regular launches (iterations 2.."
                                          "maxiter of every level) of the timed steps",
                                "first_iteration_launch_us": t_first * 1e6,
+                               "measured_stream_read_GBps": stream_gbps.value,
+                               "frac_of_measured_stream_read": alg / t_kernel / 1e9 / max(stream_gbps.value, 1e-9),
                                "algorithmic_bytes_per_launch": alg, "us_per_launch": t_kernel * 1e6,
                                "per_level_kernel_us": [float(x) / nl * 1e3 for x in ev_kernel],
                                "per_level_regular_kernel_us":

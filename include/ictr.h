@@ -28,6 +28,7 @@
 #define ICTR_H
 
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -65,6 +66,9 @@ int ictr_version(void);
 /* number of usable HIP devices (0 when none); never fails */
 int ictr_device_count(void);
 int ictr_set_device(int device);
+/* measured streaming-read bandwidth of the current GPU in GB/s (bytes >= 1 MiB read reps times with wide loads):
+ * the practical HBM ceiling to quote next to the vendor peak in roofline reports */
+int ictr_stream_read_bandwidth(size_t bytes, int reps, double *gbps_out);
 
 /* ------------------------------------------------------------------ CamClass (camera.h:19-31, camera.cpp:14-45) */
 typedef struct ictr_cam ictr_cam;

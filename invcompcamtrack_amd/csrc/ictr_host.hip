@@ -20,6 +20,7 @@ void launch_pyr_copy(const float *, float *, int, int, int, int, hipStream_t);
 void launch_pyr_down(const float *, int, int, int, float *, int, int, int, int, hipStream_t);
 void launch_pyr_finish(float *, float *, float *, int, int, int, int, int, int, hipStream_t);
 void launch_pyr_pack(const float *, const float *, const float *, float *, size_t, hipStream_t);
+void launch_stream_read(const float *, size_t, float *, hipStream_t);
 void launch_getpatch(const float *, const float *, const float *, const float *, int, int, int, int, float *, float *,
                      float *, hipStream_t);
 void launch_project_generic(const float *, float *, float *, int, int, const float *, LevelCam, hipStream_t);
@@ -74,6 +75,36 @@ extern "C" int ictr_device_count(void) {
 }
 extern "C" int ictr_set_device(int device) {
   HIPCHK(hipSetDevice(device));
+  return ICTR_OK;
+}
+static int need_device();
+// Measured streaming-read bandwidth of this GPU in GB/s: `bytes` of freshly allocated memory (>> the 256 MB Infinity
+// Cache) read `reps` times with plain wide loads. A yardstick for roofline reports next to the vendor peak.
+extern "C" int ictr_stream_read_bandwidth(size_t bytes, int reps, double *gbps_out) {
+  if (!gbps_out || bytes < (1u << 20) || reps < 1) return fail(ICTR_ERR_INVALID, "stream_read_bandwidth: bad arguments");
+  if (int rc = need_device()) return rc;
+  float *buf = nullptr, *sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc((void **)&buf, bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&sink, sizeof(float) * 8192 * kBlock);
+  if (e == hipSuccess) e = hipMemset(buf, 0, bytes);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float ms = 0.0f;
+  if (e == hipSuccess) {
+    launch_stream_read(buf, bytes / 4, sink, nullptr);  // warm-up
+    e = hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) launch_stream_read(buf, bytes / 4, sink, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (buf) (void)hipFree(buf);
+  if (sink) (void)hipFree(sink);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "stream_read_bandwidth: %s", hipGetErrorString(e));
+  *gbps_out = (double)bytes * reps / (ms * 1e-3) / 1e9;
   return ICTR_OK;
 }
 static int need_device() {

@@ -1164,6 +1164,30 @@ void launch_pyr_down(const float *src, int pw, int ph, int psw, float *dst, int 
                      hipStream_t s) {
   hipLaunchKernelGGL(k_pyr_down, grid2d(w, h), dim3(kBlock), 0, s, src, pw, ph, psw, dst, w, h, pad, sw);
 }
+// plain streaming read (16-byte non-temporal loads, 8 in flight per lane): the practical HBM read ceiling of the
+// box, reported next to the vendor peak (ictr_stream_read_bandwidth)
+__global__ __launch_bounds__(kBlock) void k_stream_read(const f32x4_t *__restrict__ src, size_t nvec, float *sink) {
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, nth = (size_t)gridDim.x * kBlock;
+  float acc = 0.0f;
+  size_t i = tid;
+  for (; i + 7 * nth < nvec; i += 8 * nth) {
+    f32x4_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + i + u * nth);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+  }
+  for (; i < nvec; i += nth) {
+    const f32x4_t v = __builtin_nontemporal_load(src + i);
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  if (acc == 1.2345e30f) sink[tid] = acc;
+}
+void launch_stream_read(const float *src, size_t nfloats, float *sink, hipStream_t s) {
+  hipLaunchKernelGGL(k_stream_read, dim3(8192), dim3(kBlock), 0, s, reinterpret_cast<const f32x4_t *>(src), nfloats / 4,
+                     sink);
+}
+
 // interleave a finished level into {img, dx, dy, 0} texels (read by k_ref8's packed taps)
 __global__ __launch_bounds__(kBlock) void k_pyr_pack(const float *__restrict__ img, const float *__restrict__ dx,
                                                      const float *__restrict__ dy, f32x4_t *pack, size_t n) {
