@@ -1287,8 +1287,10 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
     if (first && defer_h(e, variant)) {
       if (e.dopatchnorm)
         hipLaunchKernelGGL((k_iter8<true, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
-      else
+      else if (ku == 2)
         hipLaunchKernelGGL((k_iter8<false, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
+      else
+        hipLaunchKernelGGL((k_iter8<false, 4, true, true>), g8, blk, 0, s, e, lc, level, cpw);
     } else if (e.dopatchnorm)
       hipLaunchKernelGGL((k_iter8<true, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
