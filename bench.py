@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--psz", type=int, default=8)
     ap.add_argument("--maxiter", type=int, default=10)
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (bit0: LDS-staged current-frame window)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel-selection bits for A/B runs (include/ictr.h, ictr_odometer_set_variant)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
     ap.add_argument("--no-pipeline", action="store_true",

@@ -171,7 +171,14 @@ int ictr_odometer_trace(ictr_odometer *odo, ictr_trace_rec *out, int64_t capacit
 int ictr_odometer_read_buffer(ictr_odometer *odo, int which, float *host_out, int64_t count);
 /* normalisation parameters of the last Set3Dpoints */
 int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double *varval);
-/* kernel variant for A/B runs: bit0 = stage the current-frame window through LDS */
+/* Kernel-selection bits for A/B measurements and cross-checks (0 = the tuned default; results are the same up to
+ * summation order unless noted):
+ *   bit 1 (2)      any-size kernels for P = 8 instead of the wave64 = 8x8-patch fast path
+ *   bits 4-5       patches per pipeline step of the iteration kernel: 1 -> 1, 2 -> 2, 3 -> 4 with temporal loads
+ *   bits 6-7       patches per pipeline step of the setup kernel: 2 -> 1, 3 -> 4 (default 2)
+ *   bit 8 (256)    H accumulated by the setup kernel instead of by the level's first iteration launch
+ *   bits 9-11      ablation switches of the setup kernel (no stores / one plane / no taps): WRONG RESULTS, timing only
+ *   bit 12 (4096)  three separate reference planes instead of the packed {img,dx,dy,0} texels */
 int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
 int ictr_odometer_set_robust(ictr_odometer *odo, int flags, float huber_k); /* see ictr_batch_set_robust */
 
@@ -196,7 +203,7 @@ int ictr_batch_get_poses(ictr_batch *b, double *p_out);
 /* number of GN iterations each problem executed in the last track, per level summed: iters[nproblems] */
 int ictr_batch_get_iterations(ictr_batch *b, int *iters);
 int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out /* 2*M */);
-int ictr_batch_set_variant(ictr_batch *b, int variant);
+int ictr_batch_set_variant(ictr_batch *b, int variant); /* bits: see ictr_odometer_set_variant */
 /* Behaviour-changing robustness options, all OFF by default (the default reproduces the reference, quirks included).
  * flags: ICTR_ROBUST_CLEAN  points outside the reference view at a level contribute nothing (the reference reuses
  *                           their stale patches and sd coefficients, odometer.cpp:304);

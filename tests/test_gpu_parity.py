@@ -404,3 +404,28 @@ def test_full_size_properties(oracle, wh):
     tr.set3dpoints(sc["pts3d"].copy())
     tr.setpose(sc["p_a"], oracle.Pyramid(sc["img_a"], 2, 8), oracle.Pyramid(sc["img_b"], 2, 8))
     assert np.abs(tr.trackpose() - poses[0]).max() <= POSE_TOL
+
+
+def test_maxiter_zero_and_timing_getters(oracle):
+    """maxiter = 0: no iteration launch at all (with deferred H nothing ever sums H), the pose comes back as the
+    float32 round trip of the input, like the reference's loop that never runs (odometer.cpp:344-346)."""
+    sc = scene(256, 224, 64, seed=5, margin=20.0)
+    op = ic.optparam(2, 0, 8, 0, 0.0, 0, 0, 64)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    b = ic.TrackBatch(cam, op, 1)
+    b.Set3Dpoints(0, sc["pts3d"].copy())
+    b.SetPose(0, sc["p_a"], ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8))
+    b.track_async()
+    assert np.array_equal(b.poses()[0], sc["p_a"].astype(np.float32).astype(np.float64))
+    assert list(b.iterations()) == [0]
+    # per-launch event timing: first launch of a level reported separately from the sum
+    op2 = ic.optparam(2, 0, 8, 3, 0.0, 0, 0, 64)
+    b2 = ic.TrackBatch(cam, op2, 1)
+    b2.set_timing(True)
+    b2.Set3Dpoints(0, sc["pts3d"].copy())
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    b2.SetPose(0, sc["p_a"], pa, pb)
+    b2.track_async()
+    b2.poses()
+    tot, first = b2.kernel_times(), b2.first_iter_times()
+    assert np.all(first > 0) and np.all(tot > first)
