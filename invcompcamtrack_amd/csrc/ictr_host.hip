@@ -637,7 +637,13 @@ static void batch_free(ictr_batch *b) {
 }
 
 // kernel-selection bits as the launchers see them: any robustness option routes P = 8 through the any-size kernels
-static int engine_variant(const ictr_batch *b) { return b->variant | (b->robust ? 2 : 0); }
+static int engine_variant(const ictr_batch *b) {
+  static const int env_or = [] {  // ICTR_VARIANT_OR: OR extra selection bits into every engine (whole-suite A/B runs)
+    const char *v = getenv("ICTR_VARIANT_OR");
+    return v ? atoi(v) : 0;
+  }();
+  return b->variant | env_or | (b->robust ? 2 : 0);
+}
 static EngineDev engine_dev(const ictr_batch *b) {
   EngineDev e;
   e.B = b->B;
