@@ -1062,6 +1062,316 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   }
 }
 
+// ================================================================ P = 4 fast path (wave64 == four 4x4 patches)
+// The reference's other standard patch size (run_odometer_test.m:140: "4 0 4 5 0.01 0 0"). Same two-stage,
+// software-pipelined form as the 8x8 kernels; a wave-step handles FOUR consecutive patches, one per 16-lane group
+// (lane = 16 * sub + 4 * row + col): the four patches' T/Gx/Gy rows are one contiguous 256-byte row, the window
+// base and the LDS record index are per lane (gathered with ds_bpermute instead of v_readlane), validity and
+// visibility are per-lane predicates instead of wave-uniform branches. Requires the packed reference planes.
+struct TapLoads4x4 {  // one patch group per 16 lanes; a/b of the own row, top row for the lanes of patch row 0
+  f32x2_a4 ab, top;
+};
+__device__ __forceinline__ TapLoads4x4 taps4_issue(gconst_f32 plane, int idx, int sw, bool ok, bool toprow) {
+  TapLoads4x4 t;
+  f32x2_a4 z = {0.0f, 0.0f};
+  t.ab = z;
+  t.top = z;
+  if (ok) {
+    t.ab = *reinterpret_cast<gconst_f32x2>(plane + (idx - 1));
+    if (toprow) t.top = *reinterpret_cast<gconst_f32x2>(plane + (idx - sw - 1));
+  }
+  return t;
+}
+__device__ __forceinline__ float taps4_blend(const TapLoads4x4 &t, float w0, float w1, float w2, float w3, bool toprow) {
+  const float a = t.ab.y, b = t.ab.x;
+  const float cu = __shfl_up(a, 4, 64), du = __shfl_up(b, 4, 64);  // the lane one patch row up (same 16-lane group)
+  const float c = toprow ? t.top.y : cu, d = toprow ? t.top.x : du;
+  return w0 * a + w1 * b + w2 * c + w3 * d;
+}
+struct TapLoadsP4 {
+  f32x4_t l, r, tl, tr;
+};
+__device__ __forceinline__ float tapsP4_blend(const TapLoadsP4 &t, int k, float w0, float w1, float w2, float w3, bool toprow) {
+  const float a = t.r[k], b = t.l[k];
+  const float cu = __shfl_up(a, 4, 64), du = __shfl_up(b, 4, 64);
+  const float c = toprow ? t.tr[k] : cu, d = toprow ? t.tl[k] : du;
+  return w0 * a + w1 * b + w2 * c + w3 * d;
+}
+
+template <int kU>
+struct Iter4Loads {
+  float t[kU], gx[kU], gy[kU];
+  TapLoads4x4 cur[kU];
+  int jj[kU];  // per lane: index of its patch inside the chunk, or -1
+};
+
+template <bool PN, bool WH>
+__global__ __launch_bounds__(kBlock) void k_iter4(EngineDev e, LevelCam lc, int level, int cpw) {
+  constexpr int kU = 2;
+  __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
+  __shared__ float sW[kWaves][kPartBStride];
+  __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
+  const int b = blockIdx.y;
+  const ProbState &st = e.st[b];
+  if (!st.active) return;
+  const int npts = st.npts;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
+  const float *__restrict__ T = e.T + (size_t)b * M * 16;
+  const float *__restrict__ Gx = e.Gx + (size_t)b * M * 16;
+  const float *__restrict__ Gy = e.Gy + (size_t)b * M * 16;
+  const float *__restrict__ coefb = e.coef + (size_t)b * M * kCoefStride;
+  gconst_f32 cur = (gconst_f32)pl.cur;
+  const int sw = lc.sw;
+
+  float G[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = st.G[k];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane >> 4, q = lane & 15;
+  const bool toprow = q < 4;
+  const int loff = (q >> 2) * sw + (q & 3);
+  float *rec = sRec[wave];
+  const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
+
+  float acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+  float accH[WH ? kHUnique : 1];
+#pragma unroll
+  for (int j = 0; j < (WH ? kHUnique : 1); ++j) accH[j] = 0.0f;
+
+  const int nchunks = (npts + cpw - 1) / cpw;
+  for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+    const int i0 = ch * cpw;
+    const int cnt = min(cpw, npts - i0);
+    // ---- stage 1: lane j <-> point i0 + j (as k_iter8, half-size 2)
+    const bool pv = lane < cnt;
+    const int ip = i0 + (pv ? lane : 0);
+    const float X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
+    const float4 *c4 = reinterpret_cast<const float4 *>(coefb + (size_t)ip * kCoefStride);
+    const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2];
+    const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
+    const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
+    const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
+    const float mx = (tx / tz) * lc.fx + lc.cx;
+    const float my = (ty / tz) * lc.fy + lc.cy;
+    const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 2);
+    const int base_v = tp.row0 * sw + tp.col0;
+    {
+      float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
+      r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
+      r4[1] = make_float4(q0.x, q0.z, q0.w, q1.x);
+      r4[2] = make_float4(q1.y, q1.w, q2.x, q2.y);
+      r4[3] = make_float4(q2.z, q2.w, vis ? 1.0f : 0.0f, 0.0f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 2: wave-steps of four patches; kU wave-steps per pipeline step, nsteps apart
+    const int nws = (cnt + 3) >> 2;
+    const int nsteps = (nws + kU - 1) / kU;
+    auto issue = [&](Iter4Loads<kU> &L, int sidx) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int ws = sidx + u * nsteps;
+        const int j = 4 * ws + sub;
+        const bool ok = (ws < nws) & (j < cnt);
+        L.jj[u] = ok ? j : -1;
+        const int base = __shfl(base_v, ok ? j : 0, 64);
+        const size_t po = (size_t)(i0 + 4 * min(ws, nws - 1)) * 16;  // wave-uniform: 4 patches = one 256-byte row
+        L.t[u] = L.gx[u] = L.gy[u] = 0.0f;
+        if (ok) {
+          L.t[u] = __builtin_nontemporal_load(T + po + lane);
+          L.gx[u] = __builtin_nontemporal_load(Gx + po + lane);
+          L.gy[u] = __builtin_nontemporal_load(Gy + po + lane);
+        }
+        L.cur[u] = taps4_issue(cur, base + loff, sw, ok, toprow);
+      }
+    };
+    auto reduce = [&](const Iter4Loads<kU> &L) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool ok = L.jj[u] >= 0;
+        const int ri = (ok ? L.jj[u] : 0) * 4;
+        const float4 w = rec4[ri + 0], k0 = rec4[ri + 1], k1 = rec4[ri + 2], k2 = rec4[ri + 3];
+        float inew = taps4_blend(L.cur[u], w.x, w.y, w.z, w.w, toprow);
+        if constexpr (PN) inew -= group_sum(inew, 16) / 16.0f;  // utilities.cpp:111-112
+        const float r = ok ? (L.t[u] - inew) * k2.z : 0.0f;  // pdiff (odometer.cpp:381); k2.z = 0 out of the new view
+        const float gx = L.gx[u], gy = L.gy[u];                // zero for lanes without a patch
+        {
+#pragma clang fp contract(fast)
+          acc[0] += (gx * k0.x) * r;
+          acc[1] += (gy * k1.y) * r;
+          acc[2] += (gx * k0.y + gy * k1.z) * r;
+          acc[3] += (gx * k0.z + gy * k1.w) * r;
+          acc[4] += (gx * k0.w + gy * k2.x) * r;
+          acc[5] += (gx * k1.x + gy * k2.y) * r;
+          if constexpr (WH) {
+            float sd[6];
+            sd[0] = gx * k0.x;
+            sd[1] = gy * k1.y;
+            sd[2] = gx * k0.y + gy * k1.z;
+            sd[3] = gx * k0.z + gy * k1.w;
+            sd[4] = gx * k0.w + gy * k2.x;
+            sd[5] = gx * k1.x + gy * k2.y;
+            int jk = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c = a; c < 6; ++c) accH[jk++] += sd[a] * sd[c];
+          }
+        }
+      }
+    };
+    Iter4Loads<kU> A, B;
+    issue(A, 0);
+    for (int sidx = 0; sidx < nsteps; sidx += 2) {
+      if (sidx + 1 < nsteps) issue(B, sidx + 1);
+      reduce(A);
+      if (sidx + 2 < nsteps) issue(A, sidx + 2);
+      if (sidx + 1 < nsteps) reduce(B);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) sW[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] =
+        (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+  if constexpr (WH) {
+#pragma unroll
+    for (int j = 0; j < kHUnique; ++j) {
+      const float v = wave_sum(accH[j]);
+      if (lane == 0) sWH[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kHUnique)
+      e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] =
+          (sWH[0][threadIdx.x] + sWH[1][threadIdx.x]) + (sWH[2][threadIdx.x] + sWH[3][threadIdx.x]);
+  }
+}
+
+template <int kU>
+struct Ref4Loads {
+  TapLoadsP4 p4[kU];
+  int jj[kU];   // per lane: patch index inside the chunk, -1 = none
+  int vis[kU];  // per lane: that patch is inside the reference view at this level
+};
+
+// steps 4-5 for 4x4 patches (H deferred to the first k_iter4<.., WH = true> launch; packed reference planes)
+template <bool PN>
+__global__ __launch_bounds__(kBlock) void k_ref4(EngineDev e, LevelCam lc, int level, int cpw) {
+  constexpr int kU = 2;
+  const int b = blockIdx.y;
+  const ProbState &st = e.st[b];
+  const int npts = st.npts;
+  const int M = e.M;
+  const PlaneSet pl = e.planes[b * e.nlev + level];
+  const float *__restrict__ pt2d = e.pt2d + ((size_t)b * e.nlev + level) * 2 * M;
+  const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
+  float *T = e.T + (size_t)b * M * 16;
+  float *Gx = e.Gx + (size_t)b * M * 16;
+  float *Gy = e.Gy + (size_t)b * M * 16;
+  float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  gconst_f32x4 ppack = (gconst_f32x4)pl.pack;
+  const int sw = lc.sw;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane >> 4, q = lane & 15;
+  const bool toprow = q < 4;
+  const int loff = (q >> 2) * sw + (q & 3);
+
+  const int nchunks = (npts + cpw - 1) / cpw;
+  for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
+    const int i0 = ch * cpw;
+    const int cnt = min(cpw, npts - i0);
+    // ---- stage 1: one point per lane: visibility (odometer.cpp:273-282), sd coefficients (:313-326)
+    const bool pv = lane < cnt;
+    const int ip = i0 + (pv ? lane : 0);
+    const float mx = pt2d[ip], my = pt2d[ip + M];
+    const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+    if (vis) {  // invisible points keep their stale coefficients (odometer.cpp:304): nothing to do for them
+      float cx[6], cy[6];
+      sd_coefs(p3r[ip], p3r[ip + M], p3r[ip + 2 * M], lc.fx, lc.fy, cx, cy);
+      float4 *c4 = reinterpret_cast<float4 *>(coefb + (size_t)ip * kCoefStride);
+      c4[0] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+      c4[1] = make_float4(cx[4], cx[5], cy[0], cy[1]);
+      c4[2] = make_float4(cy[2], cy[3], cy[4], cy[5]);
+    }
+    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 2);
+    const int base_v = tp.row0 * sw + tp.col0;
+    const int vis_v = vis ? 1 : 0;
+    const float w0 = tp.w0, w1 = tp.w1, w2 = tp.w2, w3 = tp.w3;
+
+    // ---- stage 2: wave-steps of four patches (utilities.cpp:115-189)
+    const int nws = (cnt + 3) >> 2;
+    const int nsteps = (nws + kU - 1) / kU;
+    auto issue = [&](Ref4Loads<kU> &L, int sidx) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int ws = sidx + u * nsteps;
+        const int j = 4 * ws + sub;
+        const bool ok = (ws < nws) & (j < cnt);
+        const int js = ok ? j : 0;
+        L.jj[u] = ok ? j : -1;
+        const int v = __shfl(vis_v, js, 64);
+        const int base = __shfl(base_v, js, 64);
+        L.vis[u] = (ok && v) ? 1 : 0;
+        f32x4_t z = {0.0f, 0.0f, 0.0f, 0.0f};
+        L.p4[u].l = L.p4[u].r = L.p4[u].tl = L.p4[u].tr = z;
+        if (L.vis[u]) {
+          gconst_f32x4 pp = ppack + (base + loff);
+          L.p4[u].l = pp[-1];
+          L.p4[u].r = pp[0];
+          if (toprow) {
+            L.p4[u].tl = pp[-sw - 1];
+            L.p4[u].tr = pp[-sw];
+          }
+        }
+      }
+    };
+    auto reduce = [&](const Ref4Loads<kU> &L, int sidx) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int ws = sidx + u * nsteps;
+        const int js = L.jj[u] >= 0 ? L.jj[u] : 0;
+        const float a0 = __shfl(w0, js, 64), a1 = __shfl(w1, js, 64), a2 = __shfl(w2, js, 64), a3 = __shfl(w3, js, 64);
+        float t = tapsP4_blend(L.p4[u], 0, a0, a1, a2, a3, toprow);
+        const float gx = tapsP4_blend(L.p4[u], 1, a0, a1, a2, a3, toprow);
+        const float gy = tapsP4_blend(L.p4[u], 2, a0, a1, a2, a3, toprow);
+        if constexpr (PN) t -= group_sum(t, 16) / 16.0f;  // utilities.cpp:187-188
+        if (L.vis[u]) {
+          const size_t po = (size_t)(i0 + 4 * ws) * 16;
+          __builtin_nontemporal_store(t, T + po + lane);
+          __builtin_nontemporal_store(gx, Gx + po + lane);
+          __builtin_nontemporal_store(gy, Gy + po + lane);
+        }
+      }
+    };
+    Ref4Loads<kU> A, B;
+    issue(A, 0);
+    for (int sidx = 0; sidx < nsteps; sidx += 2) {
+      if (sidx + 1 < nsteps) issue(B, sidx + 1);
+      reduce(A, sidx);
+      if (sidx + 2 < nsteps) issue(A, sidx + 2);
+      if (sidx + 1 < nsteps) reduce(B, sidx + 1);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- util_getPatch(_grad) for callers (NCC scoring etc.)
 __global__ __launch_bounds__(kBlock) void k_getpatch(const float *__restrict__ img, const float *__restrict__ dx,
                                                      const float *__restrict__ dy, const float *__restrict__ mids,
@@ -1225,7 +1535,10 @@ void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hi
 // Deferred H (P = 8 fast path, default): the setup kernel only gathers and stores the patches; the 21 H sums are
 // accumulated by the level's first iteration launch, which streams Gx, Gy and the coefficients anyway. Variant bit 8
 // (256) keeps H in the setup kernel (the previous form, kept for A/B and as a cross-check in the tests).
-bool defer_h(const EngineDev &e, int variant) { return e.P == 8 && !(variant & 2) && !(variant & 256); }
+// wave64 fast paths: 8x8 always, 4x4 when every reference pyramid carries the packed planes
+static bool fast8(const EngineDev &e, int variant) { return e.P == 8 && !(variant & 2); }
+static bool fast4(const EngineDev &e, int variant) { return e.P == 4 && e.packed && !(variant & 2); }
+bool defer_h(const EngineDev &e, int variant) { return (fast8(e, variant) && !(variant & 256)) || fast4(e, variant); }
 // (the host sets variant bit 1 whenever a robustness option is on, see engine_variant in ictr_host.hip)
 
 // steps 4-6 of one level for every problem: accumulate kernel + per-problem tail
@@ -1266,6 +1579,12 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
       hipLaunchKernelGGL((k_ref8<false, 1, false>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);  // A/B: temporal stores
     else
       hipLaunchKernelGGL((k_ref8<false, 1>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
+  } else if (fast4(e, variant)) {
+    nblk = gridx8;
+    if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_ref4<true>), dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
+    else
+      hipLaunchKernelGGL((k_ref4<false>), dim3(gridx8, e.B), blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
     hipLaunchKernelGGL(k_ref_level<4>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
@@ -1301,6 +1620,17 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
       hipLaunchKernelGGL((k_iter8<false, 4, false>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal loads
     else
       hipLaunchKernelGGL((k_iter8<false, 4>), g8, blk, 0, s, e, lc, level, cpw);
+  } else if (fast4(e, variant)) {
+    const dim3 g8(gridx8, e.B);
+    if (first) {
+      if (e.dopatchnorm)
+        hipLaunchKernelGGL((k_iter4<true, true>), g8, blk, 0, s, e, lc, level, cpw);
+      else
+        hipLaunchKernelGGL((k_iter4<false, true>), g8, blk, 0, s, e, lc, level, cpw);
+    } else if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_iter4<true, false>), g8, blk, 0, s, e, lc, level, cpw);
+    else
+      hipLaunchKernelGGL((k_iter4<false, false>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
     hipLaunchKernelGGL((k_iter<4>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
@@ -1308,7 +1638,7 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
 }
 // ... and steps 9b-10 (one workgroup per problem)
 void launch_iter_tail(const EngineDev &e, int level, int gridx, int variant, int gridx8, int first, hipStream_t s) {
-  const int nblk = (e.P == 8 && !(variant & 2)) ? gridx8 : gridx;
+  const int nblk = (fast8(e, variant) || fast4(e, variant)) ? gridx8 : gridx;
   hipLaunchKernelGGL(k_iter_tail, dim3(e.B), dim3(kBlock), 0, s, e, level, nblk, (first && defer_h(e, variant)) ? 1 : 0);
 }
 void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,

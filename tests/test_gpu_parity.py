@@ -183,6 +183,22 @@ def test_fast_path_equals_generic_path(oracle):
             assert np.abs(po - pg).max() <= POSE_TOL
             res.append((pg, pr.odo.read_buffer(0, 64 * 300), pr.odo.read_buffer(1, 64 * 300),
                         pr.odo.read_buffer(7, 16 * 300), pr.odo.trace()))
+    # the 4x4 fast path (k_ref4 / k_iter4: four patches per wave-step) against the any-size kernels
+    res4 = []
+    for variant in (0, 2):
+        for dpn in (0, 1):
+            pr = Pair(oracle, sc, 2, 0, 4, 6, 0.0, 0, dpn, variant=variant)
+            pr.set_points()
+            pr.set_pose()
+            po, pg = pr.track()
+            assert np.abs(po - pg).max() <= POSE_TOL
+            res4.append((pg, pr.odo.read_buffer(0, 16 * 300), pr.odo.read_buffer(1, 16 * 300),
+                         pr.odo.read_buffer(2, 16 * 300), pr.odo.read_buffer(7, 16 * 300), pr.odo.trace()))
+    for k in (0, 1):
+        fast, gen = res4[k], res4[2 + k]
+        assert np.abs(fast[0] - gen[0]).max() <= 2e-6
+        assert all(np.array_equal(fast[i], gen[i]) for i in (1, 2, 3, 4))
+        assert rel(fast[5][0]["H"], gen[5][0]["H"]) <= SUM_TOL and rel(fast[5][0]["b"], gen[5][0]["b"]) <= SUM_TOL
     for k in (0, 1):
         fast = res[k]
         for other in (res[2 + k], res[4 + k]):
