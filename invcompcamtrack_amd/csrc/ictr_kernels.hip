@@ -1105,9 +1105,8 @@ struct Iter4Loads {
   int jj[kU];  // per lane: index of its patch inside the chunk, or -1
 };
 
-template <bool PN, bool WH>
+template <bool PN, bool WH, int kU = 2>
 __global__ __launch_bounds__(kBlock) void k_iter4(EngineDev e, LevelCam lc, int level, int cpw) {
-  constexpr int kU = 2;
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartBStride];
   __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
@@ -1629,6 +1628,10 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
         hipLaunchKernelGGL((k_iter4<false, true>), g8, blk, 0, s, e, lc, level, cpw);
     } else if (e.dopatchnorm)
       hipLaunchKernelGGL((k_iter4<true, false>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (((variant >> 4) & 3) == 3)
+      hipLaunchKernelGGL((k_iter4<false, false, 4>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (((variant >> 4) & 3) == 1)
+      hipLaunchKernelGGL((k_iter4<false, false, 1>), g8, blk, 0, s, e, lc, level, cpw);
     else
       hipLaunchKernelGGL((k_iter4<false, false>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (e.P == 4)
