@@ -177,7 +177,8 @@ int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double 
  *   bits 4-5       patches per pipeline step of the iteration kernel: 1 -> 1, 2 -> 2, 3 -> 4 with temporal loads
  *   bits 6-7       patches per pipeline step of the setup kernel: 2 -> 1, 3 -> 4 (default 2)
  *   bit 8 (256)    H accumulated by the setup kernel instead of by the level's first iteration launch
- *   bits 9-11      ablation switches of the setup kernel (no stores / one plane / no taps): WRONG RESULTS, timing only
+ *   bits 9-11      ablation switches of the 8x8 setup kernel (512 no stores; with bit 12 also 1024 one plane's taps for
+ *                  all three, 2048 no taps): WRONG RESULTS, timing only
  *   bit 12 (4096)  three separate reference planes instead of the packed {img,dx,dy,0} texels */
 int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
 int ictr_odometer_set_robust(ictr_odometer *odo, int flags, float huber_k); /* see ictr_batch_set_robust */
