@@ -266,12 +266,27 @@ def main():
         # collectives behind compute (dist.sharded_program) but pay the per-iteration tail/finish launches twice.
         # Which wins depends on the collective's latency on this node, so both are timed (2 steps each, max over
         # ranks) before the warm-up and the faster one is used.
-        cands = [args.groups] if args.groups else ([1, 2] if (B % 2 == 0 and B >= 2) else [1])
+        # Candidates: (collective path, groups). "direct" = RCCL called in-stream with the library's own communicator
+        # (no cross-stream event hand-off, nothing to overlap, so one group); "torch" = torch.distributed on its own
+        # stream, with one group (collective exposed) or two (hidden behind the other group's compute).
+        two = (B % 2 == 0 and B >= 2)
+        if args.groups:
+            cands = [("direct", args.groups), ("torch", args.groups)]
+        else:
+            cands = [("direct", 1), ("torch", 1)] + ([("torch", 2)] if two else [])
+        if args.rehearse_gloo:
+            cands = [c for c in cands if c[0] == "torch"]
         built, tuning = {}, {}
-        for g in cands:
+        for mode, g in cands:
             engines = inp["make_engines"](g, split=True)
-            tracker = ShardedTracker(engines, staged=args.rehearse_gloo)
-            built[g] = (engines, tracker)
+            tracker = ShardedTracker(engines, staged=args.rehearse_gloo, direct=(mode == "direct"))
+            ok = torch.tensor([1.0 if (mode == "torch" or tracker.direct is not None) else 0.0], dtype=torch.float64,
+                              device="cpu" if args.rehearse_gloo else "cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # a path is a candidate only if every rank has it
+            if float(ok.item()) < 1.0:
+                continue
+            key = f"{mode}-{g}"
+            built[key] = (engines, tracker)
             if len(cands) > 1:
                 run(1, False)
                 barrier()
@@ -281,12 +296,12 @@ def main():
                 t_g = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64,
                                    device="cpu" if args.rehearse_gloo else "cuda")
                 dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
-                tuning[g] = float(t_g.item()) / 2 * 1e3
-        best = min(tuning, key=tuning.get) if tuning else cands[0]
+                tuning[key] = float(t_g.item()) / 2 * 1e3
+        best = min(tuning, key=tuning.get) if tuning else next(iter(built))
         engines, tracker = built[best]
         built.clear()
         if rank == 0 and tuning:
-            print(f"[bench] group-count tuning (ms/step): {tuning} -> {best}", file=sys.stderr, flush=True)
+            print(f"[bench] sharded-mode tuning (ms/step): {tuning} -> {best}", file=sys.stderr, flush=True)
 
     run(args.warmup, False)
     barrier()
@@ -338,8 +353,10 @@ def main():
                        "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
                        "host_pipeline": ("2 engines alternate, host one step ahead" if (len(engines) == 2 and tracker is None)
                                          else "none"),
-                       "collective_overlap": (f"{len(engines)} group(s) of pairs per rank (groups hide each other's "
-                                              f"all-reduces); tuning ms/step: {tuning}" if tracker is not None else "n/a"),
+                       "collective": ((("RCCL in-stream (own communicator)" if tracker.direct is not None
+                                        else "torch.distributed (own stream)")
+                                       + f", {len(engines)} group(s) of pairs per rank; tuning ms/step: {tuning}")
+                                      if tracker is not None else "n/a"),
                        "parallelism": "single GPU" if (world == 1 and tracker is None) else f"points sharded x{world}, RCCL all-reduce of "
                                                                       "H (21 f32/level) and b (6 f32/iteration)"},
             "pose_err_vs_ground_truth": err,

@@ -104,12 +104,68 @@ class _Done:
         return None
 
 
+class RcclDirect:
+    """RCCL called directly (ctypes on the librccl.so PyTorch ships) with its own communicator, so that the all-reduce
+    is enqueued ON THE COMPUTE STREAM between the tail and the finish kernels. torch.distributed runs collectives on
+    its own stream and synchronises with events in both directions; measured on MI355X that costs ~24 us of idle
+    compute stream per collective even when there is nothing to wait for (profiles/r01_notes.md) -- per Gauss-Newton
+    iteration. The unique id is created on rank 0 and broadcast through the existing torch.distributed group.
+    Any failure while setting up raises, and ShardedTracker falls back to torch.distributed."""
+
+    def __init__(self, torch, dist, group=None):
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._C, self._lib = C, C.CDLL(path)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        L = self._lib
+        L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(UniqueId)], C.c_int
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        L.ncclCommInitRank.restype = C.c_int
+        L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclAllReduce.restype = C.c_int
+        L.ncclCommDestroy.argtypes, L.ncclCommDestroy.restype = [C.c_void_p], C.c_int
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = UniqueId()
+        if rank == 0 and L.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        raw = C.string_at(C.addressof(uid), 128)  # the raw 128 bytes (a c_char array read as bytes stops at a NUL)
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.addressof(uid), bytes(t.cpu().tolist()), 128)
+        self._comm = C.c_void_p()
+        rc = L.ncclCommInitRank(C.byref(self._comm), world, uid, rank)
+        if rc != 0 or not self._comm:
+            raise RuntimeError(f"ncclCommInitRank failed ({rc})")
+        self.world = world
+        # self-test before anything relies on it: the sum of ones over the ranks must be the world size
+        probe = torch.ones(4, dtype=torch.float32, device="cuda")
+        self.all_reduce_sum_f32(probe.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if not bool((probe == float(world)).all().item()):
+            raise RuntimeError(f"direct all-reduce self-test failed: {probe.tolist()} != {world}")
+
+    def all_reduce_sum_f32(self, dev_ptr, count, stream):
+        rc = self._lib.ncclAllReduce(dev_ptr, dev_ptr, count, 7, 0, self._comm, stream)  # ncclFloat32, ncclSum
+        if rc != 0:
+            raise RuntimeError(f"ncclAllReduce failed ({rc})")
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
 class ShardedTracker:
     """Drives one TrackBatch, or several (groups of problems that are software-pipelined against each other's
     collectives), in sharded mode. With the nccl (= RCCL) backend the all-reduce is asynchronous: it runs on the
     communicator's stream and ``wait()`` makes the compute stream wait, not the host."""
 
-    def __init__(self, batch, group=None, staged=False):
+    def __init__(self, batch, group=None, staged=False, direct=True):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -125,9 +181,22 @@ class ShardedTracker:
             self.reds.append(red)
             self._hosts.append(torch.zeros(b.B * RED_STRIDE, dtype=torch.float32) if staged else None)
         self.red = self.reds[0]
+        self._stream = torch.cuda.current_stream().cuda_stream
+        self.direct = None
+        import os
+        if direct and not staged and dist.get_backend(group) == "nccl" and not os.environ.get("ICTR_NO_RCCL_DIRECT"):
+            try:
+                self.direct = RcclDirect(torch, dist, group)
+            except Exception as exc:  # keep working through torch.distributed
+                import sys
+                print(f"[ictr.dist] direct RCCL unavailable ({exc!r}); using torch.distributed", file=sys.stderr)
+                self.direct = None
 
     def _allreduce_async(self, g):
         dist = self._dist
+        if self.direct is not None:  # in-stream: nothing to wait for afterwards
+            self.direct.all_reduce_sum_f32(self.reds[g].data_ptr(), self.reds[g].numel(), self._stream)
+            return _Done()
         if self.staged:
             self._hosts[g].copy_(self.reds[g])  # synchronises with the current stream
             dist.all_reduce(self._hosts[g], op=dist.ReduceOp.SUM, group=self.group)
