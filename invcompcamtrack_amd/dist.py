@@ -173,29 +173,41 @@ class ShardedTracker:
         self.batch = self.batches[0]
         self.group, self.staged = group, staged
         self.reds, self._hosts = [], []
-        for b in self.batches:
+        import os
+        want_direct = (direct and not staged and dist.get_backend(group) == "nccl"
+                       and not os.environ.get("ICTR_NO_RCCL_DIRECT"))
+        # direct path with several groups: every group gets its own stream AND its own communicator, so that one
+        # group's in-stream all-reduce (pure link latency) runs while the other group's kernels use the GPU
+        self._torch_streams = [torch.cuda.Stream() if (want_direct and len(self.batches) > 1) else None
+                               for _ in self.batches]
+        self._streams = []
+        for b, ts in zip(self.batches, self._torch_streams):
             b.enable_sharding(True)
             red = torch.zeros(b.B * RED_STRIDE, dtype=torch.float32, device="cuda")
             b.set_reduction_buffer(red.data_ptr())
-            b.set_stream(torch.cuda.current_stream().cuda_stream)
+            handle = (ts or torch.cuda.current_stream()).cuda_stream
+            b.set_stream(handle)
+            self._streams.append(handle)
             self.reds.append(red)
             self._hosts.append(torch.zeros(b.B * RED_STRIDE, dtype=torch.float32) if staged else None)
         self.red = self.reds[0]
-        self._stream = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()  # the zero-fills above ran on the current stream
         self.direct = None
-        import os
-        if direct and not staged and dist.get_backend(group) == "nccl" and not os.environ.get("ICTR_NO_RCCL_DIRECT"):
+        if want_direct:
             try:
-                self.direct = RcclDirect(torch, dist, group)
+                self.direct = [RcclDirect(torch, dist, group) for _ in self.batches]
             except Exception as exc:  # keep working through torch.distributed
                 import sys
                 print(f"[ictr.dist] direct RCCL unavailable ({exc!r}); using torch.distributed", file=sys.stderr)
                 self.direct = None
+                for b in self.batches:
+                    b.set_stream(torch.cuda.current_stream().cuda_stream)
+                self._streams = [torch.cuda.current_stream().cuda_stream for _ in self.batches]
 
     def _allreduce_async(self, g):
         dist = self._dist
         if self.direct is not None:  # in-stream: nothing to wait for afterwards
-            self.direct.all_reduce_sum_f32(self.reds[g].data_ptr(), self.reds[g].numel(), self._stream)
+            self.direct[g].all_reduce_sum_f32(self.reds[g].data_ptr(), self.reds[g].numel(), self._streams[g])
             return _Done()
         if self.staged:
             self._hosts[g].copy_(self.reds[g])  # synchronises with the current stream

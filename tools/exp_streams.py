@@ -44,5 +44,6 @@ def run(S, B=16, steps=10, w=1920, h=1080, P=8, lv_f=2, maxiter=10):
     err = max(np.abs(p[b] - scenes[(s * per + b) % 2]["p_b"]).max() for s, p in enumerate(poses) for b in range(per))
     print(json.dumps(dict(S=S, B=B, ms_per_step=dt * 1e3, gpix_s=pix / dt / 1e9, err=float(err))), flush=True)
 
+B_ = int(__import__("os").environ.get("EXP_B", "16"))
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
-    run(S)
+    run(S, B=B_)
