@@ -162,8 +162,9 @@ class RcclDirect:
 
 class ShardedTracker:
     """Drives one TrackBatch, or several (groups of problems that are software-pipelined against each other's
-    collectives), in sharded mode. With the nccl (= RCCL) backend the all-reduce is asynchronous: it runs on the
-    communicator's stream and ``wait()`` makes the compute stream wait, not the host."""
+    collectives), in sharded mode. Collective path: RcclDirect (in-stream, default when every rank can set it up),
+    else torch.distributed (asynchronous on the process group's stream; ``wait()`` makes the compute stream wait,
+    not the host), else -- ``staged`` -- through host memory with any backend (tests)."""
 
     def __init__(self, batch, group=None, staged=False, direct=True):
         import torch
@@ -200,6 +201,12 @@ class ShardedTracker:
                 import sys
                 print(f"[ictr.dist] direct RCCL unavailable ({exc!r}); using torch.distributed", file=sys.stderr)
                 self.direct = None
+            # every rank must take the same path: agree on it through the torch group
+            flag = torch.tensor([1.0 if self.direct is not None else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if float(flag.item()) < 1.0:
+                self.direct = None
+            if self.direct is None:
                 for b in self.batches:
                     b.set_stream(torch.cuda.current_stream().cuda_stream)
                 self._streams = [torch.cuda.current_stream().cuda_stream for _ in self.batches]
