@@ -21,9 +21,12 @@ the GPU runs step i (kernels never overlap; --no-pipeline restores strict altern
   cpu_baseline = the oracle (C restatement of the reference, one thread, -O3 -msse4 -mavx) timed on the same
                  workload for one frame pair (a bounded sample), on this host's cores.
 
-N > 1 (torchrun, one rank per GPU): the points of every frame pair are sharded over the ranks (each rank owns
-32 400 points per pair => weak scaling), frames are replicated, and the ranks all-reduce 21 floats of H per level
-and 6 floats of b per GN iteration per pair over RCCL (invcompcamtrack_amd/dist.py).
+N > 1 (one rank per GPU): the points of every frame pair are sharded over the ranks (each rank owns 32 400 points
+per pair => weak scaling), frames are replicated, and per pair the ranks all-reduce ONE 27-float record per GN
+iteration over RCCL (21 floats of H, filled by a level's first iteration, + 6 floats of b;
+invcompcamtrack_amd/dist.py). `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run as a child
+process, before this process touches torch or the GPU) and relays rank 0's JSON line; under torchrun (WORLD_SIZE set)
+it is a rank.
 """
 from __future__ import annotations
 
@@ -65,10 +68,69 @@ def parse():
                     help="sharded mode: also time the two-group candidates (their launches overlap on two streams)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (sharded phases + collectives) with a world of 1 (testing)")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the short secondary workloads (psz 4, full-frame affine / homography, patch flow, "
+                         "pose-sample batch, small-problem latency) reported under \"secondary\"")
+    ap.add_argument("--secondary-seconds", type=float, default=1.0, help="time budget of each secondary record")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="ranks only join a gloo group and all-reduce one number (CPU test of the --gpus N launcher)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on ONE GPU: all ranks use cuda:0 and the 27*B floats are all-reduced through "
                          "host memory with gloo (same kernels, same phase sequence; numbers are not a benchmark)")
     return ap.parse_args()
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` from a plain shell: become the launcher. Nothing here imports torch or touches HIP (a
+    process that has initialised the GPU must not be replaced or forked into ranks); the ranks are fresh children of
+    `python -m torch.distributed.run`. Rank 0 writes the JSON line to its stdout, which is relayed; the exit code is
+    the children's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] launching ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        print(f"[bench] ranks failed with exit code {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("[bench] ranks finished without a result line", file=sys.stderr)
+        return 1
+    return 0
+
+
+def launcher_selftest(args):
+    """--selftest-launcher: the rank side of a launcher check that needs no GPU (tests/test_bench_launcher_cpu.py):
+    gloo process group, one all-reduce, rank 0 prints a JSON line shaped like the real one."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("ICTR_SELFTEST_FAIL_RANK") == str(rank):  # the test of "a failing rank fails the launcher"
+        raise SystemExit(7)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest", "n_gpus": world, "value": float(t.item()),
+                          "gpus_arg": args.gpus, "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def build_inputs(args, rank, world):
@@ -131,7 +193,7 @@ def cpu_baseline(args, scene, n_pts):
         t0 = time.perf_counter()
         tr.set3dpoints(pts)
         tr.setpose(scene["p_a"], pa, pb)
-        tr.trackpose()
+        p_cpu = np.array(tr.trackpose(), np.float64)
         t_used += time.perf_counter() - t0
         runs += 1
         if time.perf_counter() > t_end or runs >= 1000:
@@ -144,7 +206,7 @@ def cpu_baseline(args, scene, n_pts):
                 break
     except OSError:
         pass
-    return {"value": pix_per_run * runs / t_used / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+    return p_cpu, {"value": pix_per_run * runs / t_used / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
             "cpu_model": cpu_model, "host_cores": os.cpu_count(),
             "gn_iters_per_s": args.levels * args.maxiter * runs / t_used,
             "sample": f"{runs} full trackings of one {args.width}x{args.height} frame pair ({n_pts} points, "
@@ -154,6 +216,13 @@ def cpu_baseline(args, scene, n_pts):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))  # before anything touches torch.cuda / HIP in this process
+    if args.selftest_launcher:
+        sys.exit(launcher_selftest(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world wins",
+              file=sys.stderr, flush=True)
     # The contract is ONE JSON line on stdout. Native libraries write there too (RCCL prints a five-line version
     # banner on its first collective), so everything that goes to fd 1 during the run is sent to stderr and the
     # result line is written to the saved descriptor at the end.
@@ -393,7 +462,7 @@ def main():
                                       if sharded else "n/a"),
                        "concurrent_streams": (len(engines) if (tracker is not None and not sharded) else 1),
                        "parallelism": "single GPU" if (world == 1 and not sharded) else f"points sharded x{world}, RCCL all-reduce of "
-                                                                      "H (21 f32/level) and b (6 f32/iteration)"},
+                                                                      "one 27-float record (H 21 + b 6) per pair per iteration"},
             "pose_err_vs_ground_truth": err,
         }
         if not args.no_events:
@@ -408,32 +477,50 @@ def main():
             n_reg = args.steps * n_eng_step * (args.maxiter - 1) * args.levels
             n_first = args.steps * n_eng_step * args.levels
             nl = args.steps * n_eng_step * args.maxiter
-            t_kernel = float(ev_kernel.sum() - ev_first.sum()) / max(n_reg, 1) * 1e-3  # s per launch, kernel alone
+            n_all = n_reg + n_first
+            t_all = float(ev_kernel.sum()) / max(n_all, 1) * 1e-3          # s per launch, EVERY k_iter8 launch
+            t_kernel = float(ev_kernel.sum() - ev_first.sum()) / max(n_reg, 1) * 1e-3  # regular instantiation alone
             t_first = float(ev_first.sum()) / max(n_first, 1) * 1e-3
             if n_reg == 0:
                 t_kernel = t_first
             alg = 16.0 * pix_per_iter * pairs_per_launch
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-            if os.path.exists(tpath):
+            # unique bytes: T, Gx, Gy are 12 B per patch pixel at every level; the current-frame texel is unique only
+            # at level 0 (8-px grid = patch size). At level l the centres are 8/2^l px apart, so the 8x8 patches
+            # overlap 4^l-fold and a launch touches 4 / 4^l B of distinct frame bytes per patch pixel.
+            lv_l = 0
+            uniq_bpp = [12.0 + 4.0 / (4.0 ** l) for l in range(lv_l, lv_l + args.levels)]
+            traffic, traffic_source = None, None
+            for tname in ("traffic_r02.json", "traffic_r01.json"):
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if not os.path.exists(tpath):
+                    continue
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts and tracker is None:
                         traffic = tj.get("hbm_bytes_per_launch_mean")
+                        traffic_source = (f"profiles/{tname}: rocprofv3 --pmc passes of this command collected in "
+                                          "their own runs (FETCH_SIZE x 2 + WRITE_SIZE); static, NOT measured in this run")
+                        break
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": alg / t_kernel / 1e9, "peak": 8000.0, "unit": "GB/s",
-                               "frac": alg / t_kernel / 1e9 / 8000.0, "traffic": traffic,
-                               "kernel": "k_iter8 (GN iteration: steps 7-9a), mean over the regular launches (iterations 2.."
-                                         "maxiter of every level) of the timed steps",
+            per_level_all = [float(x) / nl * 1e3 for x in ev_kernel]
+            out["roofline"] = {"bound": "hbm", "achieved": alg / t_all / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": alg / t_all / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                               "kernel": "k_iter8 (GN iteration: steps 7-9a), mean over ALL its launches of the timed "
+                                         "steps (both instantiations: the first launch of a level also sums H)",
+                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_all * 1e6,
+                               "launches_timed": n_all,
+                               "regular_launch_us": t_kernel * 1e6, "regular_launch_frac": alg / t_kernel / 1e9 / 8000.0,
                                "first_iteration_launch_us": t_first * 1e6,
                                "note": ("launches of different engines overlap on the GPU: the durations are wall-clock "
                                         "durations of launches that share the machine, not solo durations"
                                         if (tracker is not None and len(engines) > 1) else None),
                                "measured_stream_read_GBps": stream_gbps.value,
-                               "frac_of_measured_stream_read": alg / t_kernel / 1e9 / max(stream_gbps.value, 1e-9),
-                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_kernel * 1e6,
-                               "per_level_kernel_us": [float(x) / nl * 1e3 for x in ev_kernel],
+                               "frac_of_measured_stream_read": alg / t_all / 1e9 / max(stream_gbps.value, 1e-9),
+                               "per_level_kernel_us": per_level_all,
+                               "per_level_bytes_unique_per_px": uniq_bpp,
+                               "per_level_unique_GBps": [b_ * pix_per_iter * pairs_per_launch / (u * 1e-6) / 1e9 if u > 0 else None
+                                                         for b_, u in zip(uniq_bpp, per_level_all)],
                                "per_level_regular_kernel_us":
                                    [float(x - y) / max(args.steps * n_eng_step * (args.maxiter - 1), 1) * 1e3
                                     for x, y in zip(ev_kernel, ev_first)],
@@ -441,12 +528,29 @@ def main():
                                    [float(x) / nl * 1e3 for x in ev_iters] if tracker is None else None,
                                "per_level_setup_us":
                                    [float(x) / args.steps * 1e3 for x in ev_setup] if tracker is None else None}
-        if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, scenes[0], n_pts)
+        pose_fail = False
+        if args.cpu_seconds > 0 and world == 1 and not sharded:
+            # the same tracking on the CPU path (the oracle: checker and baseline, never the product): problem 0 is
+            # scene 0 with its unmodified points, so its pose is directly comparable (north star: <= 1e-4)
+            p_cpu, out["cpu_baseline"] = cpu_baseline(args, scenes[0], n_pts)
+            out["pose_err_vs_cpu"] = float(np.abs(np.asarray(poses[0], np.float64) - p_cpu).max())
+            out["pose_err_vs_cpu_bar"] = 1e-4
+            pose_fail = not (out["pose_err_vs_cpu"] <= 1e-4)
         else:
             out["cpu_baseline"] = None  # measured on rank 0 at N=1 only
+            out["pose_err_vs_cpu"] = None
+        if args.secondary and world == 1 and not sharded:
+            import gc as _gc
+            del engines, tracker
+            _gc.collect()
+            from tools import secondary as sec
+            out["secondary"] = sec.run_all(args.secondary_seconds)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if pose_fail:
+            print(f"[bench] FAIL: pose differs from the CPU path by {out['pose_err_vs_cpu']:.3e} > 1e-4",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -227,6 +227,9 @@ int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters);
 int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel);
 /* ms per level of the level's FIRST accumulate launch alone (8x8 fast path: the instantiation that also sums H) */
 int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first);
+/* which launch form the last tracking used: 0 = per-iteration launches (large problems), 1 = the one-launch tracker
+ * (whole odometer.cpp:257-426 loop in one kernel, one workgroup per problem; chosen for small problems) */
+int ictr_batch_last_path(const ictr_batch *b);
 
 /* ---- distributed (points sharded over ranks): split phases so the caller can all-reduce ----
  * The normal-equation block lives in a caller-visible device buffer: per problem 21 floats of H
@@ -254,6 +257,8 @@ int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on th
  * status (optional) 1/0; iters (optional) executed iterations. Build-defined algorithm: no reference pins it. */
 int ictr_patchflow(const ictr_pyramid *pyr_a, const ictr_pyramid *pyr_b, const float *pts, int64_t K, int psz, int lv_f,
                    int lv_l, int maxiter, float eps, float *out, int *status, int *iters);
+/* duration in ms of the k_patchflow launch of this thread's last ictr_patchflow call (HIP events), < 0 if unknown */
+float ictr_patchflow_last_kernel_ms(void);
 
 /* ------------------------------------------------------------------ full-frame parametric alignment (extension)
  * Inverse-compositional Gauss-Newton alignment of a whole template region under one parametric warp:

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ictr_batch_get_level_times": (C.c_int, [VP, FP, FP]),
     "ictr_batch_get_kernel_times": (C.c_int, [VP, FP]),
     "ictr_batch_get_first_iter_times": (C.c_int, [VP, FP]),
+    "ictr_batch_last_path": (C.c_int, [VP]),
     "ictr_batch_set_reduction_buffer": (C.c_int, [VP, VP]),
     "ictr_batch_enable_sharding": (C.c_int, [VP, C.c_int]),
     "ictr_batch_reduction_buffer": (VP, [VP]),
@@ -127,6 +128,7 @@ SIGNATURES = {
     "ictr_batch_iter_accumulate": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_finish": (C.c_int, [VP, C.c_int]),
     "ictr_patchflow": (C.c_int, [VP, VP, FP, I64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, IP, IP]),
+    "ictr_patchflow_last_kernel_ms": (C.c_float, []),
     "ictr_icgn_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, IP,
                                    I64]),
     "ictr_icgn_destroy": (None, [VP]),

@@ -32,6 +32,8 @@ void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, i
 void launch_iter_tail(const EngineDev &, int, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
+hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, hipStream_t);
+size_t track1_plan(int, int, int, int *);
 }  // namespace ictr
 
 namespace ictr {
@@ -609,6 +611,8 @@ struct ictr_batch {
   std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
   int evk_iters = 0;
   int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
+  int maxpts = 0;    // largest nopoints over the problems of the current tracking (set by ictr_batch_begin)
+  int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip)
   int phase_it = 0;  // iteration counter of the phase API (event slot of the next iter_accumulate)
   float *d_red_own = nullptr;
   // results of the last track_async: the final states are copied to pinned host memory in-stream and an event marks
@@ -896,6 +900,7 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
     }
   }
   b->packed = all_packed ? 1 : 0;
+  b->maxpts = maxpts;
   {
     // P=8 fast path geometry: a wave owns `cpw` consecutive points. Small problems get small chunks (more
     // waves, latency hidden by occupancy); large batches get 64-point chunks (coalesced stage 1, deep ILP).
@@ -993,10 +998,44 @@ extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
   return ICTR_OK;
 }
 
+// Small problems (the reference's own sizes: 50-1000 points per pair) run the whole coarse-to-fine loop in ONE launch,
+// one workgroup per problem (ictr_track1.hip): below ~1000 points the per-iteration launch pairs are pure
+// dependent-launch latency. Not for sharded batches (they need collectives between phases) and not when per-launch
+// event timing is on. Variant bit 13 forces the per-iteration launches, bit 14 the one-launch tracker.
+static bool use_track1(const ictr_batch *b) {
+  const int v = engine_variant(b);
+  if (b->sharded || b->timing || (v & 8192)) return false;
+  if (b->maxpts < 1 || (size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS
+  if (v & 16384) return true;
+  static const int limit = [] {
+    const char *s = getenv("ICTR_TRACK1_MAXPTS");
+    return s ? atoi(s) : 1024;
+  }();
+  return (int64_t)b->maxpts * b->n <= (int64_t)limit * 64;
+}
+static int track1_waves(const ictr_batch *b) {
+  static const int forced = [] {
+    const char *s = getenv("ICTR_TRACK1_WAVES");
+    return s ? atoi(s) : 0;
+  }();
+  if (forced > 0) return forced;
+  const int ppw = (b->n <= 64 && 64 % b->n == 0) ? 64 / b->n : 1;
+  const int groups = (b->maxpts + ppw - 1) / ppw;
+  return std::min(8, std::max(4, (groups + 3) / 4));
+}
+
 // split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket
 // the accumulate kernel alone
 static int enqueue_levels(ictr_batch *b) {
   const EngineDev e = engine_dev(b);
+  b->last_path = 0;
+  if (use_track1(b)) {
+    LevelCam cams[16];
+    for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
+    HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), b->stream));
+    b->last_path = 1;
+    return ICTR_OK;
+  }
   if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
   const int mi = b->op->maxiter;
   const bool tk = b->timing && (int)b->evk.size() >= 2 * b->nlev * mi && mi <= b->evk_iters;
@@ -1093,6 +1132,7 @@ extern "C" int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first) {
   }
   return ICTR_OK;
 }
+extern "C" int ictr_batch_last_path(const ictr_batch *b) { return b ? b->last_path : -1; }
 extern "C" int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   b->d_red = dev_ptr ? dev_ptr : b->d_red_own;
@@ -1258,6 +1298,8 @@ extern "C" int ictr_batch_read_buffer(ictr_batch *b, int64_t problem, int which,
     case 5: src = b->d_pt3d_ref + pr * 3 * M; avail = 3 * M; break;
     case 7: src = b->d_coef + pr * M * kCoefStride; avail = M * kCoefStride; break;
     case 8: src = reinterpret_cast<const float *>(b->d_st + pr); avail = sizeof(ProbState) / sizeof(float); break;
+    case 9: src = b->d_partH + pr * 8; avail = 8; break;  // k_track1 phase cycle counters (ICTR_T1_PROF builds only)
+    case 10: src = b->d_partH + (size_t)b->B * 8 + pr * 4; avail = 4; break;  // ... and the solver's
     default:
       if (which >= 100 && which < 100 + b->nlev) {
         src = b->d_pt2d + (pr * b->nlev + (size_t)(which - 100)) * 2 * M;
@@ -1281,6 +1323,8 @@ extern "C" int ictr_odometer_get_norm(const ictr_odometer *o, double *meanshift3
 }
 
 // ---------------------------------------------------------------- per-patch translation IC-LK (flow producer)
+static thread_local float g_pf_ms = -1.0f;
+extern "C" float ictr_patchflow_last_kernel_ms(void) { return g_pf_ms; }
 extern "C" int ictr_patchflow(const ictr_pyramid *pa, const ictr_pyramid *pb, const float *pts, int64_t K, int psz,
                               int lv_f, int lv_l, int maxiter, float eps, float *out, int *status, int *iters) {
   if (!pa || !pb || K < 0 || (K > 0 && (!pts || !out)) || psz < 1 || psz > 32 || lv_l < 0 || lv_f < lv_l || maxiter < 0)
@@ -1323,8 +1367,14 @@ extern "C" int ictr_patchflow(const ictr_pyramid *pa, const ictr_pyramid *pb, co
   a.iters = d_iters;
   hipError_t e = hipMemcpy(d_pts, pts, sizeof(float) * 2 * K, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
+    static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;  // duration of the one kernel, for callers that report it
+    if (!ev0 && (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)) ev0 = ev1 = nullptr;
+    if (ev0) (void)hipEventRecord(ev0, nullptr);
     launch_patchflow(a, nullptr);
+    if (ev0) (void)hipEventRecord(ev1, nullptr);
     e = hipMemcpy(out, d_out, sizeof(float) * 2 * K, hipMemcpyDeviceToHost);
+    g_pf_ms = -1.0f;
+    if (ev0 && e == hipSuccess && hipEventElapsedTime(&g_pf_ms, ev0, ev1) != hipSuccess) g_pf_ms = -1.0f;
     if (e == hipSuccess && status) e = hipMemcpy(status, d_status, sizeof(int) * K, hipMemcpyDeviceToHost);
     if (e == hipSuccess && iters) e = hipMemcpy(iters, d_iters, sizeof(int) * K, hipMemcpyDeviceToHost);
   }

@@ -27,157 +27,10 @@
 #include <algorithm>
 
 #include "ictr_dev.h"
+#include "ictr_devfn.h"
 #include "se3_math.h"
 
 namespace ictr {
-
-// ---------------------------------------------------------------- small device helpers
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-// sum over aligned groups of `width` lanes (width = power of two <= 64)
-__device__ __forceinline__ float group_sum(float v, int width) {
-  for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
-struct Taps {
-  float w0, w1, w2, w3;
-  int col0, row0;
-};
-
-// utilities.cpp:66-77 : patch-constant bilinear weights, ceil(x+1e-5f) tap selection
-__device__ __forceinline__ Taps make_taps(float mx, float my, int pszd2) {
-  Taps t;
-  const int p0 = (int)ceilf(mx + .00001f);
-  const int p1 = (int)ceilf(my + .00001f);
-  const int p2 = (int)floorf(mx);
-  const int p3 = (int)floorf(my);
-  const float r0 = mx - (float)p2;
-  const float r1 = my - (float)p3;
-  t.w0 = r0 * r1;
-  t.w1 = (1 - r0) * r1;
-  t.w2 = r0 * (1 - r1);
-  t.w3 = (1 - r0) * (1 - r1);
-  t.col0 = p0 + pszd2;
-  t.row0 = p1 + pszd2;
-  return t;
-}
-
-// utilities.cpp:107 : a=(col,row) b=(col-1,row) c=(col,row-1) d=(col-1,row-1)
-__device__ __forceinline__ float tap4(const float *__restrict__ img, int idx, int sw, const Taps &t) {
-  const float a = img[idx], b = img[idx - 1], c = img[idx - sw], d = img[idx - sw - 1];
-  return t.w0 * a + t.w1 * b + t.w2 * c + t.w3 * d;
-}
-
-__device__ __forceinline__ bool in_view(float mx, float my, float swo, float sho) {
-  // odometer.cpp:273-276 rejects (x<0)|(y<0)|(x>swo)|(y>sho); written positively so NaN is "outside"
-  return (mx >= 0.0f) & (my >= 0.0f) & (mx <= swo) & (my <= sho);
-}
-
-// odometer.cpp:313-326 : per-point steepest-descent coefficients; the "1.0 +" terms are f64, narrowed
-__device__ __forceinline__ void sd_coefs(float X, float Y, float Z, float fx, float fy, float *cx, float *cy) {
-  const float zsq = Z * Z;
-  cx[0] = fx / Z;
-  cy[0] = 0.0f;
-  cx[1] = 0.0f;
-  cy[1] = fy / Z;
-  cx[2] = -X / zsq * fx;
-  cy[2] = -Y / zsq * fy;
-  cx[3] = -X * Y / zsq * fx;
-  cy[3] = (float)((-(1.0 + (double)(Y * Y / zsq))) * (double)fy);
-  cx[4] = (float)((1.0 + (double)(X * X / zsq)) * (double)fx);
-  cy[4] = X * Y / zsq * fy;
-  cx[5] = -Y / Z * fx;
-  cy[5] = X / Z * fy;
-}
-
-__device__ __forceinline__ void sd_values(float gx, float gy, const float *cx, const float *cy, float *sd) {
-  sd[0] = gx * cx[0];
-  sd[1] = gy * cy[1];
-#pragma unroll
-  for (int k = 2; k < 6; ++k) sd[k] = gx * cx[k] + gy * cy[k];
-}
-
-// once per level and problem, one thread: factor the new H (ws: 36 floats of LDS holding H, destroyed)
-__device__ void level_factor(ProbState &st, float *ws, int *iws) {
-  lu_factor_ws<6>(ws, iws, iws + 12);
-  for (int k = 0; k < 36; ++k) st.LU[k] = ws[k];
-  for (int k = 0; k < 12; ++k) st.piv[k] = iws[k];
-  st.luinfo[0] = iws[12];
-  st.luinfo[1] = iws[13];
-}
-
-__device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
-  // odometer.cpp:341-346
-  st.normdp_init = 1e-10f;
-  st.normdp = 1e-10f;
-  st.it = 0;
-  st.active = ((0 < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
-}
-
-// steps 9b + 10 + loop condition, one thread. ws: LDS workspace of 64 floats: [0..35] LU factors, [36..41] b,
-// [42..47] scratch, [48..59] transpositions, [60..61] info. Everything runtime-indexed lives in LDS: private arrays
-// would go to scratch memory.
-__device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, int prob, float *ws) {
-  float dp[6];
-  const int *iws = reinterpret_cast<const int *>(ws + 48);
-  lu_apply_ws<6>(ws, iws, iws + 12, ws + 36, dp, ws + 42);
-  float p[6];
-  float G[12];
-  if (e.robust & ICTR_ROBUST_COMPOSE) {  // option: left-compositional update G <- exp(dp) G, p = log(G)
-    float D[12], Go[12];
-    se3_exp<float>(D, dp);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Go[k] = st.G[k];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        G[r * 4 + c] = D[r * 4 + 0] * Go[c] + D[r * 4 + 1] * Go[4 + c] + D[r * 4 + 2] * Go[8 + c] + (c == 3 ? D[r * 4 + 3] : 0.0f);
-    }
-    se3_log<float>(p, G);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      st.dp[k] = dp[k];
-      st.p[k] = p[k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      st.dp[k] = dp[k];
-      p[k] = st.p[k] + dp[k];  // pose.cpp:118-123 additive update
-      st.p[k] = p[k];
-    }
-  }
-  se3_exp<float>(G, p);
-#pragma unroll
-  for (int k = 0; k < 12; ++k) st.G[k] = G[k];
-  // delta_p.lpNorm<1>() : Eigen's unrolled redux tree for 6 coefficients
-  const float nd = (fabsf(dp[0]) + (fabsf(dp[1]) + fabsf(dp[2]))) + (fabsf(dp[3]) + (fabsf(dp[4]) + fabsf(dp[5])));
-  st.normdp = nd;
-  if (st.it == 0) st.normdp_init = nd;
-  if (e.trace.rec != nullptr && prob == 0) {
-    const int c = *e.trace.count;
-    if (c < e.trace.capacity) {
-      ictr_trace_rec &r = e.trace.rec[c];
-      r.level = level;
-      r.iter = st.it;
-      for (int k = 0; k < 36; ++k) r.H[k] = st.H[k];
-      for (int k = 0; k < 6; ++k) {
-        r.b[k] = st.b[k];
-        r.dp[k] = dp[k];
-        r.p[k] = p[k];
-      }
-    }
-    *e.trace.count = c + 1;
-  }
-  st.it += 1;
-  st.total_iters += 1;
-  st.active = ((st.it < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
-}
 
 // ---------------------------------------------------------------- step 3: projection at the reference pose
 // pose.cpp:400-488 (save rotated, level lv_f) + pose.cpp:307-397 for the other levels (odometer.cpp:251-254).
@@ -636,41 +489,6 @@ __global__ void k_iter_finish(EngineDev e, int level, int first_h) {
 //            base, the frame window is read with every cache line requested once, the per-patch constants come
 //            back from LDS as broadcast ds_read_b128. The steps are software-pipelined (double-buffered
 //            registers): the loads of step s+1 are in flight while step s is reduced.
-typedef const float __attribute__((address_space(1))) *gconst_f32;  // plane pointers come out of a table in memory:
-                                                                    // tell the compiler they are global, not flat
-typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-typedef const f32x2_a4 __attribute__((address_space(1))) *gconst_f32x2;
-
-__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ float rlane(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
-constexpr int kRec = 16;  // floats per point record in LDS: [w0 w1 w2 w3][cx0 cx2 cx3 cx4][cx5 cy1 cy2 cy3][cy4 cy5 vis -]
-
-// The four bilinear taps of a lane's pixel (lanes = 8x8 pixels, row-major) with every cache line of the 9x9 window
-// requested once: one 8-byte load per lane gives (b,a) of its own row; lanes 0..7 also load the row above; all
-// other lanes take (d,c) from the lane one row up (ds_bpermute) when the values are consumed.
-struct TapLoads {
-  f32x2_a4 ab, top;
-};
-__device__ __forceinline__ TapLoads taps_issue(gconst_f32 plane_at_base, int loff, int sw, int lane) {
-  TapLoads t;
-  t.ab = *reinterpret_cast<gconst_f32x2>(plane_at_base + (loff - 1));
-  f32x2_a4 q = {0.0f, 0.0f};
-  if (lane < 8) q = *reinterpret_cast<gconst_f32x2>(plane_at_base + (loff - sw - 1));
-  t.top = q;
-  return t;
-}
-// utilities.cpp:107 with the reference's operand order, never contracted: template and current patch must round
-// identically so that identical frames give a residual of exactly zero (identity KAT)
-__device__ __forceinline__ float taps_blend(const TapLoads &t, float w0, float w1, float w2, float w3, int lane) {
-  const float a = t.ab.y, b = t.ab.x;
-  const float cu = __shfl_up(a, 8, 64), du = __shfl_up(b, 8, 64);
-  const float c = lane < 8 ? t.top.y : cu, d = lane < 8 ? t.top.x : du;
-  return w0 * a + w1 * b + w2 * c + w3 * d;
-}
-
 // XCD-aware workgroup order. The hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its
 // own L2. Re-labelling id -> (id % 8) * (n / 8) + id / 8 gives every XCD a contiguous band of chunks, so neighbouring
 // chunks (which share frame cache lines at their borders) meet in one L2 instead of being fetched twice from the

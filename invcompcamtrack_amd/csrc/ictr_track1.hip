@@ -1,0 +1,955 @@
+// ictr_track1.hip -- the WHOLE coarse-to-fine tracking of a small problem in ONE launch (gfx950 / CDNA4).
+//
+// The reference's own operating point is 50-1000 points per frame pair (run_odometer_test.m:140,232: every 10th
+// visible point; odometer.cpp:156-167 times 100 patches). At that size the per-iteration launch pairs of
+// ictr_kernels.hip are pure dependent-launch latency (111 launches = 0.65 ms, slower than the CPU below ~150
+// points). Here one workgroup owns one problem and runs odometer.cpp:257-426 from the first level's setup to the
+// last pose update without leaving the CU:
+//
+//   per level   stage A  one POINT per thread: visibility at the reference pose (odometer.cpp:268-282), the 12
+//                        steepest-descent coefficients (:313-326; stale ones kept for points out of view, :304),
+//                        bilinear weights + window base (utilities.cpp:66-77) -> LDS point record
+//               stage B  one PATCH per wave (four 4x4 patches per wave; any other size: lanes loop over the
+//                        pixels): T/Gx/Gy gathered (utilities.cpp:115-189), stored to the global patch buffers
+//                        (they persist across frames like pat_ref_all) and, when they fit, kept in LDS; the 21 H
+//                        sums (odometer.cpp:428-472) per lane -> wave shuffle -> fixed-order f64 over the waves
+//               thread 0 full-pivot LU of H once per level (odometer.cpp:509-515), loop state reset (:341-346)
+//   per iteration stage 1  one point per thread: projection at the current pose (pose.cpp:384-391), ind_new
+//                        (odometer.cpp:369-377), weights + base -> LDS record
+//               stage 2  one patch per wave: current-frame window (utilities.cpp:55-113), residual, J^T r
+//                        (odometer.cpp:381-404) in six per-lane accumulators across all the wave's patches
+//               thread 0 fixed-order f64 sum of the wave partials, substitution with the level's LU factors, pose
+//                        update, exp map, |dp|_1 and the loop condition (odometer.cpp:407-418)
+//
+// Three workgroup barriers per iteration, no global synchronisation, no host round trip; the pose, the LU factors
+// and the per-point records never leave LDS. Independent problems (run_track_nposes' pose samples) are the grid.
+// Arithmetic: identical expressions to the per-iteration kernels (same helpers, -ffp-contract=off), so patches,
+// projections and coefficients are bit-identical to the CPU path; H and b differ from it by summation order only.
+#include <algorithm>
+
+#include "ictr_dev.h"
+#include "ictr_devfn.h"
+#include "se3_math.h"
+
+namespace ictr {
+
+constexpr int kT1MaxWaves = 8;  // 512 threads: two waves per SIMD with up to 256 registers each
+
+struct T1Args {
+  LevelCam lc[16];
+  int npts_cap;  // record / LDS template capacity in points (>= every problem's npts)
+  int dbg;       // ICTR_T1_PROF builds: ablation bits (env ICTR_T1_DBG); otherwise unused
+};
+
+struct T1Rec {  // 16 floats per point
+  float w0, w1, w2, w3;
+  float cx0, cx2, cx3, cx4;
+  float cx5, cy1, cy2, cy3;
+  float cy4, cy5, vis;
+  int base;
+};
+static_assert(sizeof(T1Rec) == 64, "record must be one 64-byte row");
+
+#ifdef ICTR_T1_PROF  // diagnostic builds only: per-phase cycle counters of thread 0 (tools/t1prof.py)
+#define T1_MARK(k)                          \
+  if (tid == 0) {                           \
+    t1_ = __builtin_readcyclecounter();     \
+    tp_[k] += t1_ - t0_;                    \
+    t0_ = t1_;                              \
+  }
+#else
+#define T1_MARK(k)
+#endif
+// wave totals of N per-lane accumulators -> dst[0..N-1] (lane k stores total k; one store instruction)
+#define T1_REDUCE_STORE(N, acc, dst)                   \
+  {                                                    \
+    float o_ = 0.0f;                                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < (N); ++k_) { \
+      const float v_ = wave_sum_dpp((acc)[k_]);        \
+      o_ = lane == k_ ? v_ : o_;                       \
+    }                                                  \
+    if (lane < (N)) (dst)[lane] = o_;                  \
+  }
+
+// ---- 8x8 patches, lane == pixel. Per-lane constants of a level (byte offsets from the window's top-left texel
+// (base - sw - 1)): the lane's own row pair (x-1,y),(x,y), and for the lanes of patch row 0 the pair one row up.
+typedef const char __attribute__((address_space(1))) *gconst_bytes;
+struct T1Lane {
+  unsigned off_ab, off_top;  // bytes
+  int up4;                   // ds_bpermute byte index of the lane one patch row up
+  bool toprow;
+};
+struct T1Win {
+  f32x2_a4 ab, top;
+};
+__device__ __forceinline__ T1Win t1_win_issue(gconst_f32 plane, int base, int sw, const T1Lane &ln) {
+  gconst_bytes p = reinterpret_cast<gconst_bytes>(plane + (base - sw - 1));  // wave-uniform: scalar base + 32-bit offset
+  T1Win w;
+  w.ab = *reinterpret_cast<gconst_f32x2>(p + ln.off_ab);
+  f32x2_a4 z = {0.0f, 0.0f};
+  w.top = z;
+  if (ln.toprow) w.top = *reinterpret_cast<gconst_f32x2>(p + ln.off_top);
+  return w;
+}
+// utilities.cpp:107, the reference's operand order, never contracted (see taps_blend)
+__device__ __forceinline__ float t1_win_blend(const T1Win &w, float w0, float w1, float w2, float w3, const T1Lane &ln) {
+  const float a = w.ab.y, b = w.ab.x;
+  const float cu = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ln.up4, __builtin_bit_cast(int, a)));
+  const float du = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ln.up4, __builtin_bit_cast(int, b)));
+  const float c = ln.toprow ? w.top.y : cu, d = ln.toprow ? w.top.x : du;
+  return w0 * a + w1 * b + w2 * c + w3 * d;
+}
+
+template <int kU> struct T1Loads {  // one pipeline step of the 8x8 iteration phase
+  T1Win cur[kU];
+  float t[kU], gx[kU], gy[kU];
+  int i[kU];  // point index, -1 = padding of a partial step (wave-uniform)
+};
+template <int kU> struct T1RefLoads {  // one pipeline step of the 8x8 level setup
+  T1Win r[kU], x[kU], y[kU];
+  float sgx[kU], sgy[kU], st[kU];  // stale patch of a point that is out of the reference view at this level
+  int i[kU];
+};
+
+// PT = 8: lane == pixel, de-duplicated window rows, no behaviour-changing options (the host routes those to PT = 0);
+// PT = 0: any patch size (run-time e.P), every option.
+// TL: the level's T/Gx/Gy patches are kept in LDS (they fit); otherwise they are re-read from the global patch
+// buffers, which the same workgroup wrote during the level setup (L2 hits). PN: dopatchnorm (PT = 8 only).
+template <int PT, bool TL, bool PN>
+__global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float sDyn[];
+  __shared__ float sPart[kT1MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
+  __shared__ float sG[12];                             // cpos_G of the current iteration
+  __shared__ int sActive;                              // loop condition, decided by wave 0
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthr >> 6;
+  const int P = PT ? PT : e.P;
+  const int n = P * P;
+  const int pszd2 = P / 2;
+  const int M = e.M;
+  const int ppw = (n <= 64 && (64 % n) == 0) ? 64 / n : 1;  // patches per wave
+  const int sub = ppw > 1 ? lane / n : 0;
+  const int q0 = ppw > 1 ? lane % n : lane;
+  const int qstride = ppw > 1 ? n : 64;
+  const int gwidth = ppw > 1 ? n : 64;
+
+  T1Rec *rec = reinterpret_cast<T1Rec *>(sDyn);
+  int *sBase = reinterpret_cast<int *>(sDyn + (size_t)a.npts_cap * 16);
+  float *lT = sDyn + (size_t)a.npts_cap * 17;   // any-size form: three planes [npts_cap * n]
+  float *lGx = lT + (size_t)a.npts_cap * n;
+  float *lGy = lGx + (size_t)a.npts_cap * n;
+  float *lTpl = lT;                              // 8x8 form: [point][T | Gx | Gy][64], one address + fixed offsets
+
+  ProbState &gst = e.st[b];
+  const int npts = gst.npts;
+  // Wave 0 is the solver: LU factors, pose and loop state stay in its registers for the whole tracking
+  // (WaveSolver, ictr_devfn.h); the other waves see only cpos_G and the loop flag, through LDS.
+  WaveSolver S;
+  float G[12];
+  S.p = lane < 6 ? gst.p[lane] : 0.0f;
+  S.b = S.dp = S.h = 0.0f;
+  S.total_iters = gst.total_iters;
+  S.normdp = S.normdp_init = 1e-10f;
+  S.it = 0;
+  S.active = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = gst.G[k];
+  if (tid < 12) sG[tid] = gst.G[tid];
+
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
+  const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
+  float *gT = e.T + (size_t)b * M * n;
+  float *gGx = e.Gx + (size_t)b * M * n;
+  float *gGy = e.Gy + (size_t)b * M * n;
+  float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  const int ngroups = (npts + ppw - 1) / ppw;
+  const int mycnt = wave < npts ? (npts - wave + nwaves - 1) / nwaves : 0;  // 8x8: patches wave, wave + nwaves, ...
+
+#ifdef ICTR_T1_PROF
+  unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = 0, t1_ = 0;
+  if (tid == 0) t0_ = __builtin_readcyclecounter();
+#endif
+  for (int sl = e.lv_f; sl >= e.lv_l; --sl) {
+    const LevelCam lc = a.lc[sl];
+    const int sw = lc.sw;
+    const PlaneSet pl = e.planes[b * e.nlev + sl];
+    T1Lane ln;
+    ln.off_ab = (unsigned)(((lane >> 3) + 1) * sw + (lane & 7)) * 4u;
+    ln.off_top = (unsigned)(lane & 7) * 4u;
+    ln.up4 = (lane >= 8 ? lane - 8 : lane) << 2;
+    ln.toprow = lane < 8;
+    // ---------------------------------------------------------------- level setup, stage A (one point per thread)
+    {
+      const float *pt2d = e.pt2d + ((size_t)b * e.nlev + sl) * 2 * M;
+      for (int i = tid; i < npts; i += nthr) {
+        const float mx = pt2d[i], my = pt2d[i + M];
+        const bool vis = in_view(mx, my, lc.swo, lc.sho);
+        float cx[6], cy[6];
+        float4 *c4 = reinterpret_cast<float4 *>(coefb + (size_t)i * kCoefStride);
+        if (vis) {
+          sd_coefs(p3r[i], p3r[i + M], p3r[i + 2 * M], lc.fx, lc.fy, cx, cy);
+          c4[0] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+          c4[1] = make_float4(cx[4], cx[5], cy[0], cy[1]);
+          c4[2] = make_float4(cy[2], cy[3], cy[4], cy[5]);
+        } else {  // stale coefficients stay in force (odometer.cpp:304); zeros if the point was never seen
+          const float4 a0 = c4[0], a1 = c4[1], a2 = c4[2];
+          cx[0] = a0.x; cx[1] = a0.y; cx[2] = a0.z; cx[3] = a0.w; cx[4] = a1.x; cx[5] = a1.y;
+          cy[0] = a1.z; cy[1] = a1.w; cy[2] = a2.x; cy[3] = a2.y; cy[4] = a2.z; cy[5] = a2.w;
+        }
+        const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, pszd2);  // (1,1): a harmless in-plane window
+        float4 *r4 = reinterpret_cast<float4 *>(&rec[i]);
+        const int base = tp.row0 * sw + tp.col0;
+        r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
+        r4[1] = make_float4(cx[0], cx[2], cx[3], cx[4]);
+        r4[2] = make_float4(cx[5], cy[1], cy[2], cy[3]);
+        r4[3] = make_float4(cy[4], cy[5], vis ? 1.0f : 0.0f, __builtin_bit_cast(float, base));
+        sBase[i] = base;
+      }
+    }
+    __syncthreads();
+    T1_MARK(0)
+    // ---------------------------------------------------------------- stage B (one patch per wave / 16-lane group)
+    {
+      float acc[kHUnique];
+#pragma unroll
+      for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
+      if constexpr (PT == 8) {
+        gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
+        constexpr int kU = 2;
+        for (int c0 = 0; c0 < mycnt; c0 += 64) {
+          const int cn = min(64, mycnt - c0);
+          const int idx = wave + (c0 + (lane < cn ? lane : 0)) * nwaves;
+          const int mybase = sBase[idx];
+          const int myvis = rec[idx].vis != 0.0f ? 1 : 0;
+          auto issue = [&](T1RefLoads<kU> &L, int k) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              const bool ok = k + u < cn;
+              const int kk = ok ? k + u : k;
+              const int i = wave + (c0 + kk) * nwaves;
+              const int base = rlane_dyn(mybase, kk);
+              const int vis = rlane_dyn(myvis, kk);
+              L.i[u] = ok ? (vis ? i : i + (1 << 24)) : -1;  // bit 24: out of the reference view (stale patch)
+              if (vis) {  // wave-uniform
+                L.r[u] = t1_win_issue(pref, base, sw, ln);
+                L.x[u] = t1_win_issue(pdx, base, sw, ln);
+                L.y[u] = t1_win_issue(pdy, base, sw, ln);
+              } else {
+                const int o = i * 64 + lane;
+                L.sgx[u] = gGx[o];
+                L.sgy[u] = gGy[o];
+                L.st[u] = gT[o];
+              }
+            }
+          };
+          auto reduce = [&](const T1RefLoads<kU> &L) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              if (L.i[u] < 0) continue;  // wave-uniform
+              const bool vis = !(L.i[u] & (1 << 24));
+              const int i = L.i[u] & ((1 << 24) - 1);
+              const float4 *r4 = reinterpret_cast<const float4 *>(&rec[i]);
+              const float4 w = r4[0], k0 = r4[1], k1 = r4[2], k2 = r4[3];
+              const int o = i * 64 + lane;
+              float t, gx, gy;
+              if (vis) {
+                t = t1_win_blend(L.r[u], w.x, w.y, w.z, w.w, ln);
+                gx = t1_win_blend(L.x[u], w.x, w.y, w.z, w.w, ln);
+                gy = t1_win_blend(L.y[u], w.x, w.y, w.z, w.w, ln);
+                if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188 (same order as k_ref8)
+                gT[o] = t;
+                gGx[o] = gx;
+                gGy[o] = gy;
+              } else {  // stale patch stays in force (odometer.cpp:304)
+                t = L.st[u];
+                gx = L.sgx[u];
+                gy = L.sgy[u];
+              }
+              if constexpr (TL) {
+                float *d = lTpl + i * 192 + lane;
+                d[0] = t;
+                d[64] = gx;
+                d[128] = gy;
+              }
+              {
+#pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
+                float sd[6];
+                sd[0] = gx * k0.x;
+                sd[1] = gy * k1.y;
+                sd[2] = gx * k0.y + gy * k1.z;
+                sd[3] = gx * k0.z + gy * k1.w;
+                sd[4] = gx * k0.w + gy * k2.x;
+                sd[5] = gx * k1.x + gy * k2.y;
+                int jk = 0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                  for (int kk = j; kk < 6; ++kk) acc[jk++] += sd[j] * sd[kk];
+              }
+            }
+          };
+          T1RefLoads<kU> A, B;
+          issue(A, 0);
+          for (int k = 0; k < cn; k += 2 * kU) {
+            if (k + kU < cn) issue(B, k + kU);
+            reduce(A);
+            if (k + 2 * kU < cn) issue(A, k + 2 * kU);
+            if (k + kU < cn) reduce(B);
+          }
+        }
+      } else {
+        for (int g = wave; g < ngroups; g += nwaves) {
+          const int i = g * ppw + sub;
+          const bool valid = i < npts;
+          const T1Rec r = rec[valid ? i : 0];
+          const bool vis = valid && r.vis != 0.0f;
+          Taps tp;
+          tp.w0 = r.w0; tp.w1 = r.w1; tp.w2 = r.w2; tp.w3 = r.w3;
+          const int base = r.base;
+          float cx[6], cy[6];
+          cx[0] = valid ? r.cx0 : 0.0f; cx[1] = 0.0f; cx[2] = valid ? r.cx2 : 0.0f; cx[3] = valid ? r.cx3 : 0.0f;
+          cx[4] = valid ? r.cx4 : 0.0f; cx[5] = valid ? r.cx5 : 0.0f;
+          cy[0] = 0.0f; cy[1] = valid ? r.cy1 : 0.0f; cy[2] = valid ? r.cy2 : 0.0f; cy[3] = valid ? r.cy3 : 0.0f;
+          cy[4] = valid ? r.cy4 : 0.0f; cy[5] = valid ? r.cy5 : 0.0f;
+          float mean = 0.0f;
+          if (e.dopatchnorm) {  // utilities.cpp:187-188 : intensity patch only
+            float s = 0.0f;
+            for (int q = q0; q < n; q += qstride)
+              if (vis) s += tap4(pl.ref, base + (q / P) * sw + (q % P), sw, tp);
+            s = group_sum(s, gwidth);
+            mean = s / (float)n;
+          }
+          for (int q = q0; q < n; q += qstride) {
+            float t = 0.0f, gx = 0.0f, gy = 0.0f;
+            const size_t o = (size_t)i * n + q;
+            if (vis) {
+              const int idx = base + (q / P) * sw + (q % P);
+              t = tap4(pl.ref, idx, sw, tp);
+              if (e.dopatchnorm) t -= mean;
+              gx = tap4(pl.dx, idx, sw, tp);
+              gy = tap4(pl.dy, idx, sw, tp);
+              gT[o] = t;
+              gGx[o] = gx;
+              gGy[o] = gy;
+            } else if (valid) {
+              if (e.robust & ICTR_ROBUST_CLEAN) {  // option: no stale contributions
+                gGx[o] = 0.0f;
+                gGy[o] = 0.0f;
+              } else {
+                gx = gGx[o];
+                gy = gGy[o];
+              }
+              if (TL) t = gT[o];
+            }
+            if (TL && valid) {
+              lT[o] = t;
+              lGx[o] = gx;
+              lGy[o] = gy;
+            }
+            float sd[6];
+            sd_values(gx, gy, cx, cy, sd);
+            int jk = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+              for (int k = j; k < 6; ++k) acc[jk++] += sd[j] * sd[k];
+          }
+        }
+      }
+      T1_REDUCE_STORE(kHUnique, acc, sPart[wave])
+    }
+    __syncthreads();
+    T1_MARK(1)
+    if (wave == 0) {  // odometer.cpp:457-471 + 509-515: waves added in a fixed order in f64, mirrored, factored once
+      double hs = 0.0;
+      if (lane < kHUnique)
+        for (int w = 0; w < nwaves; ++w) hs += (double)sPart[w][lane];
+      const int r = lane / 6, c = lane - 6 * r;
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      const int j = lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
+      ws_factor(S, lane_gather((float)hs, j), lane);
+      ws_level_reset(S, e);
+      if (lane == 0) sActive = S.active;
+    }
+    __syncthreads();
+    T1_MARK(2)
+    // ---------------------------------------------------------------- Gauss-Newton iterations of this level
+    const float *__restrict__ cur = pl.cur;
+    while (sActive) {  // workgroup-uniform: read after a barrier, rewritten only between barriers
+      // stage 1: projection at the current pose (pose.cpp:384-391), ind_new (odometer.cpp:369-377)
+      {
+        float Gc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Gc[k] = sG[k];
+        for (int i = tid; i < npts; i += nthr) {
+          const float X = p3[i], Y = p3[i + M], Z = p3[i + 2 * M];
+          const float tx = Gc[0] * X + Gc[1] * Y + Gc[2] * Z + Gc[3];
+          const float ty = Gc[4] * X + Gc[5] * Y + Gc[6] * Z + Gc[7];
+          const float tz = Gc[8] * X + Gc[9] * Y + Gc[10] * Z + Gc[11];
+          const float mx = (tx / tz) * lc.fx + lc.cx;
+          const float my = (ty / tz) * lc.fy + lc.cy;
+          const bool vis = in_view(mx, my, lc.swo, lc.sho);
+          const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, pszd2);
+          const int base = tp.row0 * sw + tp.col0;
+          T1Rec &r = rec[i];
+          *reinterpret_cast<float4 *>(&r) = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
+          r.vis = vis ? 1.0f : 0.0f;
+          r.base = base;
+          sBase[i] = base;
+        }
+      }
+      __syncthreads();
+      T1_MARK(3)  // stage 1 + barrier
+      // stage 2
+      float acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+      if constexpr (PT == 8) {
+        gconst_f32 curg = (gconst_f32)cur;
+        constexpr int kU = 2;
+        for (int c0 = 0; c0 < mycnt; c0 += 64) {
+          const int cn = min(64, mycnt - c0);
+          const int mybase = sBase[wave + (c0 + (lane < cn ? lane : 0)) * nwaves];
+          auto issue = [&](T1Loads<kU> &L, int k) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              const bool ok = k + u < cn;
+              const int kk = ok ? k + u : k;
+              const int i = wave + (c0 + kk) * nwaves;
+              L.i[u] = ok ? i : -1;
+              L.cur[u] = t1_win_issue(curg, rlane_dyn(mybase, kk), sw, ln);
+              if constexpr (TL) {
+                const float *tp = lTpl + i * 192 + lane;
+                L.t[u] = tp[0];
+                L.gx[u] = tp[64];
+                L.gy[u] = tp[128];
+              } else {
+                const int o = i * 64 + lane;
+                L.t[u] = gT[o];
+                L.gx[u] = gGx[o];
+                L.gy[u] = gGy[o];
+              }
+            }
+          };
+          auto reduce = [&](const T1Loads<kU> &L) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              if (L.i[u] < 0) continue;  // wave-uniform
+              const float4 *r4 = reinterpret_cast<const float4 *>(&rec[L.i[u]]);
+              const float4 w = r4[0], k0 = r4[1], k1 = r4[2], k2 = r4[3];
+              float inew = t1_win_blend(L.cur[u], w.x, w.y, w.z, w.w, ln);
+              if constexpr (PN) inew -= wave_sum_dpp(inew) / 64.0f;  // utilities.cpp:111-112
+              const float r = (L.t[u] - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 out of the new view
+              {
+#pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only
+                const float gr = L.gx[u] * r, hr = L.gy[u] * r;
+                acc[0] += gr * k0.x;                // sd1 = Gx cx0
+                acc[1] += hr * k1.y;                // sd2 = Gy cy1
+                acc[2] += gr * k0.y + hr * k1.z;    // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
+                acc[3] += gr * k0.z + hr * k1.w;
+                acc[4] += gr * k0.w + hr * k2.x;
+                acc[5] += gr * k1.x + hr * k2.y;
+              }
+            }
+          };
+          T1Loads<kU> A, B;
+          issue(A, 0);
+          for (int k = 0; k < cn; k += 2 * kU) {
+            if (k + kU < cn) issue(B, k + kU);
+            reduce(A);
+            if (k + 2 * kU < cn) issue(A, k + 2 * kU);
+            if (k + kU < cn) reduce(B);
+          }
+        }
+      } else {
+        for (int g = wave; g < ngroups; g += nwaves) {
+          const int i = g * ppw + sub;
+          const bool valid = i < npts;
+          const T1Rec r = rec[valid ? i : 0];
+          const bool vis = valid && r.vis != 0.0f;
+          Taps tp;
+          tp.w0 = r.w0; tp.w1 = r.w1; tp.w2 = r.w2; tp.w3 = r.w3;
+          const int base = r.base;
+          float cx[6], cy[6];
+          cx[0] = r.cx0; cx[1] = 0.0f; cx[2] = r.cx2; cx[3] = r.cx3; cx[4] = r.cx4; cx[5] = r.cx5;
+          cy[0] = 0.0f; cy[1] = r.cy1; cy[2] = r.cy2; cy[3] = r.cy3; cy[4] = r.cy4; cy[5] = r.cy5;
+          float mean = 0.0f;
+          if (e.dopatchnorm) {  // utilities.cpp:111-112
+            float s = 0.0f;
+            for (int q = q0; q < n; q += qstride)
+              if (vis) s += tap4(cur, base + (q / P) * sw + (q % P), sw, tp);
+            s = group_sum(s, gwidth);
+            mean = s / (float)n;
+          }
+          for (int q = q0; q < n; q += qstride) {
+            if (vis) {
+              const size_t o = (size_t)i * n + q;
+              float inew = tap4(cur, base + (q / P) * sw + (q % P), sw, tp);
+              if (e.dopatchnorm) inew -= mean;
+              float rr = (TL ? lT[o] : gT[o]) - inew;  // pdiff (odometer.cpp:381)
+              if (e.robust & ICTR_ROBUST_HUBER) {
+                const float ar = fabsf(rr);
+                if (ar > e.huber_k) rr *= e.huber_k / ar;
+              }
+              float sd[6];
+              sd_values(TL ? lGx[o] : gGx[o], TL ? lGy[o] : gGy[o], cx, cy, sd);
+#pragma unroll
+              for (int k = 0; k < 6; ++k) acc[k] += sd[k] * rr;  // sd*_proj summed (odometer.cpp:386-404)
+            }
+          }
+        }
+      }
+      T1_MARK(4)  // stage 2 of wave 0
+      T1_REDUCE_STORE(6, acc, sPart[wave])
+      __syncthreads();
+      T1_MARK(5)  // wave reduction + waiting for the other waves
+      if (wave == 0) {  // steps 9a (final sum, fixed order, f64) - 10, loop condition
+        double bs = 0.0;
+        if (lane < 6)
+          for (int w = 0; w < nwaves; ++w) bs += (double)sPart[w][lane];
+        ws_iterate(S, (float)bs, e, sl, b, lane, G);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) sG[k] = G[k];
+          sActive = S.active;
+        }
+      }
+      T1_MARK(6)  // final sum + solve + update
+      __syncthreads();
+    }
+  }
+  if (wave == 0) {  // final state back to the problem's record (the host reads p, G and the iteration count)
+    if (lane < 6) {
+      gst.p[lane] = S.p;
+      gst.b[lane] = S.b;
+      gst.dp[lane] = S.dp;
+    }
+    if (lane < 36) gst.H[lane] = S.h;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gst.G[k] = G[k];
+      gst.normdp = S.normdp;
+      gst.normdp_init = S.normdp_init;
+      gst.it = S.it;
+      gst.active = S.active;
+      gst.total_iters = S.total_iters;
+    }
+  }
+#ifdef ICTR_T1_PROF
+  if (tid == 0)
+    for (int k = 0; k < 8; ++k) e.partH[(size_t)b * 8 + k] = (float)tp_[k];
+#endif
+}
+
+// ================================================================ 8x8 patches: the lean form
+// A wave owns the points wave, wave + nwaves, ... for the whole tracking, one POINT per lane in "stage 1" (chunks of
+// 64) and one PATCH per step in "stage 2" (lane == pixel). What stage 1 computes for a point (bilinear weights,
+// window base, visibility; at level setup also the 10 non-zero steepest-descent coefficients) stays in that lane's
+// registers and reaches stage 2 through v_readlane: no LDS record, no barrier between the two stages and no LDS
+// latency on the per-patch path. The four taps of a pixel are two 8-byte loads per lane (rows y and y-1; neighbouring
+// lanes' requests coalesce in the L1), so the blend needs no cross-lane traffic. Per Gauss-Newton iteration the
+// workgroup meets at two barriers: partial sums ready, new pose ready.
+struct T8Pt {  // stage-1 results of the lane's point
+  float w0, w1, w2, w3;
+  int base;  // element index of the window's top-left texel (tap d of pixel 0): (row0 - 1) * sw + col0 - 1
+  int vis;
+};
+struct T8Coef {  // the 10 steepest-descent coefficients that are not identically zero (odometer.cpp:313-326)
+  float cx0, cx2, cx3, cx4, cx5, cy1, cy2, cy3, cy4, cy5;
+};
+struct T8Win {
+  f32x2_a4 ab, cd;  // (x-1,y),(x,y) and (x-1,y-1),(x,y-1)
+};
+__device__ __forceinline__ T8Win t8_issue(gconst_f32 plane, int base, unsigned off_cd, unsigned off_ab) {
+  gconst_bytes p = reinterpret_cast<gconst_bytes>(plane + base);  // wave-uniform base + 32-bit per-lane offsets
+  T8Win w;
+  w.cd = *reinterpret_cast<gconst_f32x2>(p + off_cd);
+  w.ab = *reinterpret_cast<gconst_f32x2>(p + off_ab);
+  return w;
+}
+// utilities.cpp:107: a=(col,row) b=(col-1,row) c=(col,row-1) d=(col-1,row-1); reference operand order, not contracted
+__device__ __forceinline__ float t8_blend(const T8Win &w, float w0, float w1, float w2, float w3) {
+  return w0 * w.ab.y + w1 * w.ab.x + w2 * w.cd.y + w3 * w.cd.x;
+}
+template <int kU> struct T8Loads {
+  T8Win cur[kU];
+  float t[kU], gx[kU], gy[kU];
+  int k[kU];  // patch index inside the chunk, -1 = padding of a partial step (wave-uniform)
+};
+template <int kU> struct T8RefLoads {
+  T8Win r[kU], x[kU], y[kU];  // visible patch: the three reference planes' windows
+  int k[kU];                  // bit 8 set: out of the reference view at this level (stale patch re-used)
+};
+__device__ __forceinline__ float rl(float v, int k) {  // v_readlane with a wave-uniform run-time lane index
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+
+template <bool TL, bool PN>
+__global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float sDyn[];
+  __shared__ float sPart[kT1MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
+  __shared__ float sG[12];                             // cpos_G of the current iteration
+  __shared__ int sActive;                              // loop condition, decided by wave 0
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int M = e.M;
+  float4 *lCoef = reinterpret_cast<float4 *>(sDyn);  // [npts_cap][3]: the 10 coefficients of a point (+ 2 pad)
+  float *lTpl = sDyn + (size_t)a.npts_cap * 12;      // [point][T | Gx | Gy][64] when TL
+
+  ProbState &gst = e.st[b];
+  const int npts = gst.npts;
+  WaveSolver S;  // wave 0 is the solver (ictr_devfn.h)
+  float G[12];
+  S.p = lane < 6 ? gst.p[lane] : 0.0f;
+  S.b = S.dp = S.h = 0.0f;
+  S.total_iters = gst.total_iters;
+  S.normdp = S.normdp_init = 1e-10f;
+  S.it = 0;
+  S.active = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = gst.G[k];
+  if (tid < 12) sG[tid] = gst.G[tid];
+
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
+  const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
+  float *gT = e.T + (size_t)b * M * 64;
+  float *gGx = e.Gx + (size_t)b * M * 64;
+  float *gGy = e.Gy + (size_t)b * M * 64;
+  float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  const int mycnt = wave < npts ? (npts - wave + nwaves - 1) / nwaves : 0;  // points wave, wave + nwaves, ...
+  float X1 = 0.0f, Y1 = 0.0f, Z1 = 1.0f;  // the lane's point when the wave has a single chunk
+  if (mycnt > 0 && mycnt <= 64) {
+    const int i1 = wave + (lane < mycnt ? lane : 0) * nwaves;
+    X1 = p3[i1], Y1 = p3[i1 + M], Z1 = p3[i1 + 2 * M];
+  }
+#ifdef ICTR_T1_PROF
+  unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = 0, t1_ = 0;
+  if (tid == 0) t0_ = __builtin_readcyclecounter();
+  const int dbg = a.dbg;
+  S.tm[0] = S.tm[1] = S.tm[2] = S.tm[3] = 0;
+#endif
+
+  for (int sl = e.lv_f; sl >= e.lv_l; --sl) {
+    const LevelCam lc = a.lc[sl];
+    const int sw = lc.sw;
+    const PlaneSet pl = e.planes[b * e.nlev + sl];
+    const unsigned off_cd = (unsigned)((lane >> 3) * sw + (lane & 7)) * 4u;  // bytes from the window's top-left texel
+    const unsigned off_ab = off_cd + (unsigned)sw * 4u;
+    constexpr int kU = 2;
+    // ---------------------------------------------------------------- level setup (odometer.cpp:268-334, 428-472)
+    {
+      float acc[kHUnique];
+#pragma unroll
+      for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
+      gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
+      const float *pt2d = e.pt2d + ((size_t)b * e.nlev + sl) * 2 * M;
+      for (int c0 = 0; c0 < mycnt; c0 += 64) {
+        const int cn = min(64, mycnt - c0);
+        // stage A: lane k <-> point i = wave + (c0 + k) nwaves
+        const bool pv = lane < cn;
+        const int ip = wave + (c0 + (pv ? lane : 0)) * nwaves;
+        const float mx = pt2d[ip], my = pt2d[ip + M];
+        const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+        float cx[6], cy[6];
+        float4 *c4 = reinterpret_cast<float4 *>(coefb + (size_t)ip * kCoefStride);
+        if (vis) {
+          sd_coefs(p3r[ip], p3r[ip + M], p3r[ip + 2 * M], lc.fx, lc.fy, cx, cy);
+          c4[0] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+          c4[1] = make_float4(cx[4], cx[5], cy[0], cy[1]);
+          c4[2] = make_float4(cy[2], cy[3], cy[4], cy[5]);
+        } else {  // stale coefficients stay in force (odometer.cpp:304); zeros if the point was never seen
+          const float4 a0 = c4[0], a1 = c4[1], a2 = c4[2];
+          cx[0] = a0.x; cx[1] = a0.y; cx[2] = a0.z; cx[3] = a0.w; cx[4] = a1.x; cx[5] = a1.y;
+          cy[0] = a1.z; cy[1] = a1.w; cy[2] = a2.x; cy[3] = a2.y; cy[4] = a2.z; cy[5] = a2.w;
+        }
+        if (pv) {  // for the iterations' stage 1
+          lCoef[ip * 3 + 0] = make_float4(cx[0], cx[2], cx[3], cx[4]);
+          lCoef[ip * 3 + 1] = make_float4(cx[5], cy[1], cy[2], cy[3]);
+          lCoef[ip * 3 + 2] = make_float4(cy[4], cy[5], 0.0f, 0.0f);
+        }
+        const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
+        const int base_v = (tp.row0 - 1) * sw + tp.col0 - 1;
+        const int vis_v = vis ? 1 : 0;
+        auto issue = [&](T8RefLoads<kU> &L, int k) {
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const bool ok = k + u < cn;
+            const int kk = ok ? k + u : k;
+            const int v = rl(vis_v, kk);
+            L.k[u] = ok ? (v ? kk : kk | 256) : -1;
+            if (v) {  // wave-uniform
+              const int base = rl(base_v, kk);
+              L.r[u] = t8_issue(pref, base, off_cd, off_ab);
+              L.x[u] = t8_issue(pdx, base, off_cd, off_ab);
+              L.y[u] = t8_issue(pdy, base, off_cd, off_ab);
+            }
+          }
+        };
+        auto reduce = [&](const T8RefLoads<kU> &L) {
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            if (L.k[u] < 0) continue;  // wave-uniform
+            const int kk = L.k[u] & 255;
+            const int i = wave + (c0 + kk) * nwaves;
+            const int o = i * 64 + lane;
+            float t, gx, gy;
+            if (!(L.k[u] & 256)) {
+              const float w0 = rl(tp.w0, kk), w1 = rl(tp.w1, kk), w2 = rl(tp.w2, kk), w3 = rl(tp.w3, kk);
+              t = t8_blend(L.r[u], w0, w1, w2, w3);
+              gx = t8_blend(L.x[u], w0, w1, w2, w3);
+              gy = t8_blend(L.y[u], w0, w1, w2, w3);
+              if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188 (same order as k_ref8)
+              gT[o] = t;
+              gGx[o] = gx;
+              gGy[o] = gy;
+            } else {  // out of the reference view: the stale patch stays in force (odometer.cpp:304)
+              t = TL ? gT[o] : 0.0f;
+              gx = gGx[o];
+              gy = gGy[o];
+            }
+            if constexpr (TL) {
+              float *d = lTpl + i * 192 + lane;
+              d[0] = t;
+              d[64] = gx;
+              d[128] = gy;
+            }
+            {
+#pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
+              float sd[6];
+              sd[0] = gx * rl(cx[0], kk);
+              sd[1] = gy * rl(cy[1], kk);
+              sd[2] = gx * rl(cx[2], kk) + gy * rl(cy[2], kk);
+              sd[3] = gx * rl(cx[3], kk) + gy * rl(cy[3], kk);
+              sd[4] = gx * rl(cx[4], kk) + gy * rl(cy[4], kk);
+              sd[5] = gx * rl(cx[5], kk) + gy * rl(cy[5], kk);
+              int jk = 0;
+#pragma unroll
+              for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int q = j; q < 6; ++q) acc[jk++] += sd[j] * sd[q];
+            }
+          }
+        };
+        T8RefLoads<kU> A, B;
+        issue(A, 0);
+        for (int k = 0; k < cn; k += 2 * kU) {
+          if (k + kU < cn) issue(B, k + kU);
+          reduce(A);
+          if (k + 2 * kU < cn) issue(A, k + 2 * kU);
+          if (k + kU < cn) reduce(B);
+        }
+      }
+      T1_MARK(0)  // setup: stage A + patches of wave 0
+      T1_REDUCE_STORE(kHUnique, acc, sPart[wave])
+    }
+    __syncthreads();
+    T1_MARK(1)  // H wave reduction + barrier
+    if (wave == 0) {  // odometer.cpp:457-471 + 509-515: waves added in a fixed order in f64, mirrored, factored once
+      double hs = 0.0;
+      if (lane < kHUnique)
+        for (int w = 0; w < nwaves; ++w) hs += (double)sPart[w][lane];
+      const int r = lane / 6, c = lane - 6 * r;
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      const int j = lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
+      ws_factor(S, lane_gather((float)hs, j), lane);
+      ws_level_reset(S, e);
+      if (lane == 0) sActive = S.active;
+    }
+    __syncthreads();
+    T1_MARK(2)  // H sum + LU
+
+    // ---------------------------------------------------------------- Gauss-Newton iterations of this level
+    gconst_f32 curg = (gconst_f32)pl.cur;
+    const bool single = mycnt <= 64;
+    float4 q01 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q11 = q01, q21 = q01;
+    if (single) {
+      const int i1 = wave + (lane < mycnt ? lane : 0) * nwaves;  // wave >= npts: mycnt = 0, index stays in the arrays
+      q01 = lCoef[i1 * 3 + 0], q11 = lCoef[i1 * 3 + 1], q21 = lCoef[i1 * 3 + 2];
+    }
+    while (sActive) {  // workgroup-uniform: read after a barrier, rewritten only between barriers
+      float acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+      float Gc[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Gc[k] = sG[k];
+      for (int c0 = 0; c0 < mycnt; c0 += 64) {
+        const int cn = min(64, mycnt - c0);
+        // stage 1: projection at the current pose (pose.cpp:384-391), ind_new (odometer.cpp:369-377)
+        const bool pv = lane < cn;
+        const int ip = wave + (c0 + (pv ? lane : 0)) * nwaves;
+        // a wave with at most 64 points (up to 512 points per problem) keeps each point's X, Y, Z and coefficients in
+        // its lane's registers for the whole level: no memory round trip in front of the projection
+        float X = X1, Y = Y1, Z = Z1;
+        float4 q0 = q01, q1 = q11, q2 = q21;
+        if (!single) {
+          X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
+          q0 = lCoef[ip * 3 + 0], q1 = lCoef[ip * 3 + 1], q2 = lCoef[ip * 3 + 2];
+        }
+        const float tx = Gc[0] * X + Gc[1] * Y + Gc[2] * Z + Gc[3];
+        const float ty = Gc[4] * X + Gc[5] * Y + Gc[6] * Z + Gc[7];
+        const float tz = Gc[8] * X + Gc[9] * Y + Gc[10] * Z + Gc[11];
+        const float mx = (tx / tz) * lc.fx + lc.cx;
+        const float my = (ty / tz) * lc.fy + lc.cy;
+        const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+        const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
+        const int base_v = (tp.row0 - 1) * sw + tp.col0 - 1;
+        const float vis_f = vis ? 1.0f : 0.0f;
+        T1_MARK(3)  // stage 1
+#ifdef ICTR_T1_PROF
+        if (dbg & 1) continue;  // ablation: no patch work at all
+#endif
+        // stage 2: one patch per step, software-pipelined
+        auto issue = [&](T8Loads<kU> &L, int k) {
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const bool ok = k + u < cn;
+            const int kk = ok ? k + u : k;
+            L.k[u] = ok ? kk : -1;
+            L.cur[u] = t8_issue(curg, rl(base_v, kk), off_cd, off_ab);
+            const int i = wave + (c0 + kk) * nwaves;
+            if constexpr (TL) {
+              const float *tpl = lTpl + i * 192 + lane;
+              L.t[u] = tpl[0];
+              L.gx[u] = tpl[64];
+              L.gy[u] = tpl[128];
+            } else {
+              const int o = i * 64 + lane;
+              L.t[u] = gT[o];
+              L.gx[u] = gGx[o];
+              L.gy[u] = gGy[o];
+            }
+          }
+        };
+        auto reduce = [&](const T8Loads<kU> &L) {
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            if (L.k[u] < 0) continue;  // wave-uniform
+            const int kk = L.k[u];
+            float inew = t8_blend(L.cur[u], rl(tp.w0, kk), rl(tp.w1, kk), rl(tp.w2, kk), rl(tp.w3, kk));
+            if constexpr (PN) inew -= wave_sum_dpp(inew) / 64.0f;  // utilities.cpp:111-112
+            const float r = (L.t[u] - inew) * rl(vis_f, kk);  // pdiff (odometer.cpp:381); 0 out of the new view
+            {
+#pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only
+              const float gr = L.gx[u] * r, hr = L.gy[u] * r;
+              acc[0] += gr * rl(q0.x, kk);                       // sd1 = Gx cx0
+              acc[1] += hr * rl(q1.y, kk);                       // sd2 = Gy cy1
+              acc[2] += gr * rl(q0.y, kk) + hr * rl(q1.z, kk);   // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
+              acc[3] += gr * rl(q0.z, kk) + hr * rl(q1.w, kk);
+              acc[4] += gr * rl(q0.w, kk) + hr * rl(q2.x, kk);
+              acc[5] += gr * rl(q1.x, kk) + hr * rl(q2.y, kk);
+            }
+          }
+        };
+        T8Loads<kU> A, B;
+        issue(A, 0);
+        for (int k = 0; k < cn; k += 2 * kU) {
+          if (k + kU < cn) issue(B, k + kU);
+          reduce(A);
+          if (k + 2 * kU < cn) issue(A, k + 2 * kU);
+          if (k + kU < cn) reduce(B);
+        }
+      }
+      T1_MARK(4)  // stage 2 of wave 0
+      T1_REDUCE_STORE(6, acc, sPart[wave])
+      __syncthreads();
+      T1_MARK(5)  // wave reduction + barrier
+      if (wave == 0) {  // steps 9a (final sum, fixed order, f64) - 10, loop condition
+        double bs = 0.0;
+        if (lane < 6)
+          for (int w = 0; w < nwaves; ++w) bs += (double)sPart[w][lane];
+        ws_iterate(S, (float)bs, e, sl, b, lane, G);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) sG[k] = G[k];
+          sActive = S.active;
+        }
+      }
+      T1_MARK(6)  // final sum + solve + update
+      __syncthreads();
+      T1_MARK(7)
+    }
+  }
+#ifdef ICTR_T1_PROF
+  if (tid == 0) {
+    for (int k = 0; k < 8; ++k) e.partH[(size_t)b * 8 + k] = (float)tp_[k];
+    for (int k = 0; k < 4; ++k) e.partH[(size_t)e.B * 8 + b * 4 + k] = (float)S.tm[k];
+  }
+#endif
+  if (wave == 0) {  // final state back to the problem's record (the host reads p, G and the iteration count)
+    if (lane < 6) {
+      gst.p[lane] = S.p;
+      gst.b[lane] = S.b;
+      gst.dp[lane] = S.dp;
+    }
+    if (lane < 36) gst.H[lane] = S.h;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gst.G[k] = G[k];
+      gst.normdp = S.normdp;
+      gst.normdp_init = S.normdp_init;
+      gst.it = S.it;
+      gst.active = S.active;
+      gst.total_iters = S.total_iters;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host-side launcher
+// LDS a workgroup needs beyond the static part; tmpl_lds is switched off when the templates do not fit.
+size_t track1_plan(int npts_cap, int n, int p8, int *tmpl_lds) {
+  const size_t recb = (size_t)npts_cap * (p8 ? 48 : 68);  // 8x8: 12 coefficient floats; else 64-byte record + base
+  const size_t tmplb = (size_t)npts_cap * n * 3 * sizeof(float);
+  const size_t budget = 150 * 1024;  // of the CU's 160 KB; the static arrays take ~1 KB
+  *tmpl_lds = (recb + tmplb <= budget) ? 1 : 0;
+  return recb + (*tmpl_lds ? tmplb : 0);
+}
+
+template <typename K>
+static hipError_t launch_t1(K kernel, size_t *granted, const EngineDev &e, const T1Args &a, int waves, size_t lds,
+                            hipStream_t s) {
+  if (lds > *granted) {  // dynamic LDS above 64 KB must be granted per function
+    const size_t want = 156 * 1024;
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+    if (rc != hipSuccess) return rc;
+    *granted = want;
+  }
+  hipLaunchKernelGGL(kernel, dim3(e.B), dim3(64 * waves), lds, s, e, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, int waves, hipStream_t s) {
+  T1Args a;
+  for (int l = 0; l < 16; ++l) a.lc[l] = cams[l < e.nlev ? l : 0];
+  a.npts_cap = (std::max(maxpts, 1) + 3) & ~3;  // keeps the LDS template arrays 16-byte aligned
+  a.dbg = 0;
+#ifdef ICTR_T1_PROF
+  if (const char *d = getenv("ICTR_T1_DBG")) a.dbg = atoi(d);
+#endif
+  const bool p8 = e.P == 8 && !e.robust;  // the lean 8x8 form; behaviour-changing options run in the any-size form
+  int tl = 0;
+  const size_t lds = track1_plan(a.npts_cap, e.n, p8 ? 1 : 0, &tl);
+  waves = std::min(std::max(waves, 1), kT1MaxWaves);
+  static size_t g[6] = {0, 0, 0, 0, 0, 0};
+  if (p8) {
+    if (e.dopatchnorm)
+      return tl ? launch_t1(&k_track1_p8<true, true>, &g[0], e, a, waves, lds, s)
+                : launch_t1(&k_track1_p8<false, true>, &g[1], e, a, waves, lds, s);
+    return tl ? launch_t1(&k_track1_p8<true, false>, &g[2], e, a, waves, lds, s)
+              : launch_t1(&k_track1_p8<false, false>, &g[3], e, a, waves, lds, s);
+  }
+  return tl ? launch_t1(&k_track1<0, true, false>, &g[4], e, a, waves, lds, s)
+            : launch_t1(&k_track1<0, false, false>, &g[5], e, a, waves, lds, s);
+}
+
+}  // namespace ictr

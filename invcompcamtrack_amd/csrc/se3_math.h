@@ -25,6 +25,14 @@ template <> struct mathfn<float> {
   static ICTR_HD float sqrt_(float x) { return sqrtf(x); }
   static ICTR_HD float sin_(float x) { return sinf(x); }
   static ICTR_HD float cos_(float x) { return cosf(x); }
+  static ICTR_HD void sincos_(float x, float *sn, float *cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(x, sn, cs);  // one argument reduction for both (same results as sinf / cosf)
+#else
+    *sn = sinf(x);
+    *cs = cosf(x);
+#endif
+  }
   static ICTR_HD float acos_(float x) { return acosf(x); }
   static ICTR_HD float tan_(float x) { return tanf(x); }
 };
@@ -32,6 +40,10 @@ template <> struct mathfn<double> {
   static ICTR_HD double sqrt_(double x) { return sqrt(x); }
   static ICTR_HD double sin_(double x) { return sin(x); }
   static ICTR_HD double cos_(double x) { return cos(x); }
+  static ICTR_HD void sincos_(double x, double *sn, double *cs) {
+    *sn = sin(x);
+    *cs = cos(x);
+  }
   static ICTR_HD double acos_(double x) { return acos(x); }
   static ICTR_HD double tan_(double x) { return tan(x); }
 };
@@ -46,9 +58,11 @@ template <typename T> ICTR_HD void se3_exp(T *G, const T *p) {
   const T s3 = (sig * sig * sig);
   T sa, sb, sc;  // sin(s)/s, (1-cos s)/s^2, (s-sin s)/s^3
   if (sig > 1e-4) {
-    sa = M::sin_(sig) / sig;
-    sb = (1 - M::cos_(sig)) / s2;
-    sc = (sig - M::sin_(sig)) / s3;
+    T sn, cs;
+    M::sincos_(sig, &sn, &cs);
+    sa = sn / sig;
+    sb = (1 - cs) / s2;
+    sc = (sig - sn) / s3;
   } else {
     sa = 1 - s2 / 6 * (1 - s2 / 20 * (1 - s2 / 42));
     sb = (T)(.5 * (1 - s2 / 12 * (1 - s2 / 30 * (1 - s2 / 56))));

@@ -19,7 +19,13 @@ from ._lib import check, fp
 from .classoftrack import oftrack
 from .tracker import Pyramid
 
-__all__ = ["track_points", "dense_flow", "good_features", "run_OF_point_track"]
+__all__ = ["track_points", "dense_flow", "good_features", "run_OF_point_track", "last_kernel_ms"]
+
+
+def last_kernel_ms():
+    """Duration of the k_patchflow launch of the last track_points call (HIP events), or None."""
+    ms = float(_lib.load().ictr_patchflow_last_kernel_ms())
+    return ms if ms >= 0 else None
 
 
 def track_points(pyr_a, pyr_b, pts, psz=15, lv_f=None, lv_l=0, maxiter=10, eps=0.01):

@@ -410,6 +410,11 @@ class TrackBatch:
         check(_lib.load().ictr_batch_get_first_iter_times(self._h, fp(a)))
         return a
 
+    def path_name(self):
+        """Launch form of the last tracking: per-iteration launches or the one-launch small-problem tracker."""
+        return {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)"}.get(
+            _lib.load().ictr_batch_last_path(self._h), "?")
+
     def set_reduction_buffer(self, dev_ptr):
         check(_lib.load().ictr_batch_set_reduction_buffer(self._h, C.c_void_p(dev_ptr or 0)))
 

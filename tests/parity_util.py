@@ -6,6 +6,11 @@ import invcompcamtrack_amd as ic
 from invcompcamtrack_amd import synth
 
 
+# OR-ed into every Pair's kernel-selection bits (tests/test_gpu_parity.py runs its cases once with the automatic
+# choice -- small problems take the one-launch tracker k_track1 -- and once with bit 13 = per-iteration launches)
+FORCE_VARIANT = 0
+
+
 class Pair:
     """One scene, one parameter set, both implementations wired like run_io_reprojection_test.cpp:189-193."""
 
@@ -20,7 +25,7 @@ class Pair:
         self.cam = ic.CamClass(lv_f + 1, sc["fc"], sc["cc"], sc["wh"], psz)
         self.pose = ic.PoseClass(self.cam, self.op)
         self.odo = ic.OdometerClass(self.pose, self.op)
-        self.odo.set_variant(variant)
+        self.odo.set_variant(variant | FORCE_VARIANT)
         self.odo.enable_trace()
         self.gpa, self.gpb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
         self.M = self.op.maxpttrack

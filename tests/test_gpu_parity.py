@@ -33,6 +33,19 @@ POSE_TOL = 1e-4
 SUM_TOL = 2e-6
 DP_TOL = 2e-3
 
+LAUNCHES = 8192   # variant bit 13: per-iteration launch pairs (k_ref* / k_iter* + tails) whatever the problem size
+ONE_LAUNCH = 16384  # variant bit 14: the one-launch tracker k_track1 (default choice for small problems)
+
+
+@pytest.fixture(params=["auto", "launches"])
+def launch_form(request):
+    """Every case below that takes this fixture runs twice: with the library's own choice (these problems are small,
+    so the whole tracking is ONE launch of k_track1) and with the per-iteration launch sequence forced."""
+    import parity_util
+    parity_util.FORCE_VARIANT = 0 if request.param == "auto" else LAUNCHES
+    yield request.param
+    parity_util.FORCE_VARIANT = 0
+
 
 def _check_setup_bit_exact(pr, levels):
     M, n = pr.M, pr.n
@@ -84,7 +97,7 @@ def _check_trace(pr, check_iters=True, traj_tol=2e-5):
     (3, 1, 8, 6, 0.0, 0, 0),     # fixed iteration count, lv_l > 0
     (2, 0, 4, 8, 0.0, 0, 1),
 ])
-def test_tracker_matches_oracle_reference_parameter_sets(oracle, args):
+def test_tracker_matches_oracle_reference_parameter_sets(oracle, args, launch_form):
     lv_f, lv_l, psz, maxiter, ratio, donorm, dpn = args
     # 256 x 224: every coordinate < 256 (no ceil(x+1e-5f) quirk), even sizes down to level 4;
     # 257 points: not a multiple of 4 -> maxpttrack padding path
@@ -108,7 +121,7 @@ def test_tracker_matches_oracle_reference_parameter_sets(oracle, args):
 
 
 @pytest.mark.parametrize("args", [(4, 0, 8, 10, 0.01, 1, 1), (4, 0, 4, 5, 0.01, 0, 0)])
-def test_tracker_matches_oracle_vga_frames(oracle, args):
+def test_tracker_matches_oracle_vga_frames(oracle, args, launch_form):
     """640 x 368 frames (coordinates beyond 256: the tap-selection quirk may fire at some iteration, see the module
     docstring): bit-exact setup, first-iteration sums, final pose."""
     lv_f, lv_l, psz, maxiter, ratio, donorm, dpn = args
@@ -127,7 +140,7 @@ def test_tracker_matches_oracle_vga_frames(oracle, args):
 
 
 @pytest.mark.parametrize("psz", [2, 16, 31, 64])
-def test_extension_patch_sizes_match_oracle(oracle, psz):
+def test_extension_patch_sizes_match_oracle(oracle, psz, launch_form):
     """Patch sizes the reference cannot run (Eigen alignment) but whose geometry it defines
     (offsets -(P - P/2) ...). Oracle = our restatement: parity unpinned by the reference."""
     sc = scene(256, 224, 40, seed=40 + psz, margin=40.0)  # < 256 px: see the module docstring
@@ -142,7 +155,7 @@ def test_extension_patch_sizes_match_oracle(oracle, psz):
     assert np.abs(po - pg).max() <= POSE_TOL
 
 
-def test_identity_kat_on_gpu(oracle):
+def test_identity_kat_on_gpu(oracle, launch_form):
     """Same image twice => delta_p == 0 => p_out == (double)(float)p_in (run_io_reprojection_test.cpp:15)."""
     sc = scene(640, 368, 100, seed=3)
     pr = Pair(oracle, sc, 3, 0, 8, 5, 0.1, 0, 0)
@@ -155,7 +168,7 @@ def test_identity_kat_on_gpu(oracle):
     assert all(np.all(r["dp"] == 0) for r in tg) and len(tg) == 4  # one iteration per level, then 0/0 stops the loop
 
 
-def test_results_are_deterministic(oracle):
+def test_results_are_deterministic(oracle, launch_form):
     sc = scene(640, 368, 300, seed=8)
     outs = []
     for _ in range(3):
@@ -176,7 +189,7 @@ def test_fast_path_equals_generic_path(oracle):
     # variant 256: fast path with H accumulated by the setup kernel instead of by the first iteration launch
     for variant in (0, 2, 256):
         for dpn in (0, 1):
-            pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, dpn, variant=variant)
+            pr = Pair(oracle, sc, 2, 0, 8, 6, 0.0, 0, dpn, variant=variant | LAUNCHES)
             pr.set_points()
             pr.set_pose()
             po, pg = pr.track()
@@ -187,7 +200,7 @@ def test_fast_path_equals_generic_path(oracle):
     res4 = []
     for variant in (0, 2):
         for dpn in (0, 1):
-            pr = Pair(oracle, sc, 2, 0, 4, 6, 0.0, 0, dpn, variant=variant)
+            pr = Pair(oracle, sc, 2, 0, 4, 6, 0.0, 0, dpn, variant=variant | LAUNCHES)
             pr.set_points()
             pr.set_pose()
             po, pg = pr.track()
@@ -208,7 +221,74 @@ def test_fast_path_equals_generic_path(oracle):
             assert rel(fast[4][0]["H"], other[4][0]["H"]) <= SUM_TOL      # H of the first level, whoever summed it
 
 
-def test_points_out_of_view_and_stale_state_across_frames(oracle):
+@pytest.mark.parametrize("cfg", [
+    (8, 300, 0, 0),    # 8x8, templates resident in LDS
+    (8, 300, 1, 0),    # ... with patch normalisation
+    (8, 900, 0, 0),    # 8x8, too many points for LDS templates: re-read from the (L2-resident) global patch buffers
+    (4, 301, 0, 0),    # 4x4: four patches per wave, ragged last group
+    (4, 301, 1, 1),    # ... patch normalisation + cloud normalisation
+    (16, 40, 0, 0),    # any-size form: lanes loop over the pixels
+    (31, 24, 1, 0),    # odd size
+])
+def test_one_launch_tracker_equals_per_iteration_launches(oracle, cfg):
+    """k_track1 (whole odometer.cpp:257-426 loop in one kernel, one workgroup per problem) against the per-iteration
+    launch sequence and against the oracle: identical element-wise buffers (patches, coefficients), H and b to the
+    summation-order bar, same iteration counts, poses to float noise."""
+    psz, npts, dpn, donorm = cfg
+    sc = scene(256, 224, npts, seed=50 + psz, margin=float(max(12, psz + 9)))
+    out = []
+    for variant in (ONE_LAUNCH, LAUNCHES):
+        pr = Pair(oracle, sc, 2, 0, psz, 6, 0.0, donorm, dpn, variant=variant)
+        pr.set_points()
+        pr.set_pose()
+        po, pg = pr.track()
+        assert np.abs(po - pg).max() <= POSE_TOL
+        nv = pr.op.novals
+        out.append((pg, [pr.odo.read_buffer(w, nv * pr.n) for w in (0, 1, 2)], pr.odo.read_buffer(7, 16 * pr.n),
+                    pr.odo.trace(), pr.odo.read_buffer(8, 40)))
+        if variant == ONE_LAUNCH:
+            _check_patches(pr, exact_T=not dpn)
+            _check_trace(pr, traj_tol=POSE_TOL if psz > 8 else 2e-5)
+    one, many = out
+    assert np.abs(one[0] - many[0]).max() <= 5e-6
+    assert all(np.array_equal(a, b) for a, b in zip(one[1], many[1])), "patch buffers differ between the launch forms"
+    assert np.array_equal(one[2], many[2]), "sd coefficients differ between the launch forms"
+    assert [(r["level"], r["iter"]) for r in one[3]] == [(r["level"], r["iter"]) for r in many[3]]
+    assert rel(one[3][0]["H"], many[3][0]["H"]) <= SUM_TOL and rel(one[3][0]["b"], many[3][0]["b"]) <= SUM_TOL
+
+
+def test_one_launch_tracker_is_the_default_for_small_batches(oracle):
+    """run_track_nposes' shape: many small independent problems = one workgroup each, one launch per frame pair;
+    large problems keep the per-iteration launches."""
+    sc = scene(320, 240, 60, seed=21)
+    op = ic.optparam(2, 0, 8, 5, 0.01, 0, 0, 60)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    res = {}
+    for name, variant in (("auto", 0), ("launches", LAUNCHES)):
+        b = ic.TrackBatch(cam, op, 40)
+        b.set_variant(variant)
+        rng = np.random.default_rng(5)
+        for k in range(40):
+            b.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :20 + k].copy()))  # ragged point counts
+            b.SetPose(k, sc["p_a"] + rng.normal(0, 1e-3, 6), pa, pb)
+        b.track_async()
+        res[name] = (b.poses(), b.iterations(), b.path_name())
+    assert "k_track1" in res["auto"][2] and "k_iter" in res["launches"][2]
+    assert np.abs(res["auto"][0] - res["launches"][0]).max() <= 2e-5
+    assert np.array_equal(res["auto"][1], res["launches"][1])
+    big = scene(640, 368, 3000, seed=22)
+    opb = ic.optparam(1, 0, 8, 2, 0.0, 0, 0, 3000)
+    camb = ic.CamClass(2, big["fc"], big["cc"], big["wh"], 8)
+    bb = ic.TrackBatch(camb, opb, 1)
+    bb.Set3Dpoints(0, big["pts3d"].copy())
+    bb.SetPose(0, big["p_a"], ic.Pyramid(big["img_a"], 1, 8), ic.Pyramid(big["img_b"], 1, 8))
+    bb.track_async()
+    bb.poses()
+    assert "k_iter" in bb.path_name()
+
+
+def test_points_out_of_view_and_stale_state_across_frames(oracle, launch_form):
     """run_track_nposes chains SetPose/TrackPose without Set3Dpoints (run_track_nposes.cpp:232-258): points that
     leave the reference view keep their previous patches and sd coefficients in H and b (odometer.cpp:304).
     GPU and oracle must agree through such a chain."""
@@ -238,7 +318,7 @@ def test_points_out_of_view_and_stale_state_across_frames(oracle):
     assert np.abs(po2 - pg2).max() <= POSE_TOL * max(1.0, np.abs(po2).max())
 
 
-def test_all_points_out_of_view_gives_zero_update(oracle):
+def test_all_points_out_of_view_gives_zero_update(oracle, launch_form):
     sc = scene(320, 240, 60, seed=6)
     pr = Pair(oracle, sc, 2, 0, 8, 4, 0.0, 0, 0)
     pts = sc["pts3d"].copy()
@@ -250,7 +330,7 @@ def test_all_points_out_of_view_gives_zero_update(oracle):
     assert all(np.all(r["H"] == 0) and np.all(r["dp"] == 0) for r in pr.odo.trace())
 
 
-def test_empty_and_truncated_point_sets(oracle):
+def test_empty_and_truncated_point_sets(oracle, launch_form):
     sc = scene(320, 240, 50, seed=7)
     pr = Pair(oracle, sc, 1, 0, 8, 3, 0.0, 0, 0, maxpt=24)  # more points than maxpttrack: truncated (odometer.cpp:182)
     assert pr.M == 24
@@ -266,7 +346,7 @@ def test_empty_and_truncated_point_sets(oracle):
     assert np.array_equal(po, pg) and np.array_equal(pg, sc["p_a"].astype(np.float32).astype(np.float64))
 
 
-def test_nan_points_are_masked_not_fatal(oracle):
+def test_nan_points_are_masked_not_fatal(oracle, launch_form):
     """The reference would index out of bounds on a NaN projection; the HIP path treats it as out of view."""
     sc = scene(320, 240, 64, seed=17)
     pr = Pair(oracle, sc, 1, 0, 8, 3, 0.0, 0, 0)
