@@ -116,6 +116,14 @@ int ictr_get_patch(const ictr_pyramid *pyr, int level, const float *mids, int64_
                    float *out);
 int ictr_get_patch_grad(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz, int dopatchnorm,
                         float *out, float *out_dx, float *out_dy);
+/* run_track_nposes.cpp:271-355 -- the per-point patch correlation that scores a pose sample, on the device.
+ * For each of K points: patches around its position in the backward-most, the reference and the forward-most frame
+ * (util_getPatch with mean subtraction, :281), each divided by its norm; corr = max(0, (max(0, <b,r>) w_back +
+ * max(0, <r,f>) w_fwd) / (w_back + w_fwd)) with the reference's strict validity tests (:290-305): -1 when the
+ * reference position is outside, a term dropped (weight 0) when its frame's position is outside, 0 for NaN.
+ * mids: host SoA x_back[K] y_back[K] x_ref[K] y_ref[K] x_fwd[K] y_fwd[K] at `level`; out_corr: K floats. */
+int ictr_ncc_score(const ictr_pyramid *pyr_back, const ictr_pyramid *pyr_ref, const ictr_pyramid *pyr_fwd, int level,
+                   const float *mids, int64_t K, int psz, float w_back, float w_fwd, float *out_corr);
 
 /* ------------------------------------------------------------------ PoseClass (pose.h:18-40) */
 typedef struct ictr_pose ictr_pose;

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ictr_pyramid_device_plane": (VP, [VP, C.c_int, C.c_int]),
     "ictr_get_patch": (C.c_int, [VP, C.c_int, FP, I64, C.c_int, C.c_int, FP]),
     "ictr_get_patch_grad": (C.c_int, [VP, C.c_int, FP, I64, C.c_int, C.c_int, FP, FP, FP]),
+    "ictr_ncc_score": (C.c_int, [VP, VP, VP, C.c_int, FP, I64, C.c_int, C.c_float, C.c_float, FP]),
     "ictr_pose_create": (C.c_int, [C.POINTER(VP), VP, C.POINTER(OptParam)]),
     "ictr_pose_destroy": (None, [VP]),
     "ictr_pose_setpose_se3": (C.c_int, [VP, DP, DP, C.c_double]),

@@ -80,82 +80,12 @@ __device__ __forceinline__ void sd_values(float gx, float gy, const float *cx, c
   for (int k = 2; k < 6; ++k) sd[k] = gx * cx[k] + gy * cy[k];
 }
 
-// once per level and problem, one thread: factor the new H (ws: 36 floats of LDS holding H, destroyed)
-static __device__ void level_factor(ProbState &st, float *ws, int *iws) {
-  lu_factor_ws<6>(ws, iws, iws + 12);
-  for (int k = 0; k < 36; ++k) st.LU[k] = ws[k];
-  for (int k = 0; k < 12; ++k) st.piv[k] = iws[k];
-  st.luinfo[0] = iws[12];
-  st.luinfo[1] = iws[13];
-}
-
 __device__ __forceinline__ void level_reset(ProbState &st, const EngineDev &e) {
   // odometer.cpp:341-346
   st.normdp_init = 1e-10f;
   st.normdp = 1e-10f;
   st.it = 0;
   st.active = ((0 < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
-}
-
-// steps 9b + 10 + loop condition, one thread. ws: LDS workspace of 64 floats: [0..35] LU factors, [36..41] b,
-// [42..47] scratch, [48..59] transpositions, [60..61] info. Everything runtime-indexed lives in LDS: private arrays
-// would go to scratch memory.
-static __device__ void solve_and_update(ProbState &st, const EngineDev &e, int level, int prob, float *ws) {
-  float dp[6];
-  const int *iws = reinterpret_cast<const int *>(ws + 48);
-  lu_apply_ws<6>(ws, iws, iws + 12, ws + 36, dp, ws + 42);
-  float p[6];
-  float G[12];
-  if (e.robust & ICTR_ROBUST_COMPOSE) {  // option: left-compositional update G <- exp(dp) G, p = log(G)
-    float D[12], Go[12];
-    se3_exp<float>(D, dp);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Go[k] = st.G[k];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        G[r * 4 + c] = D[r * 4 + 0] * Go[c] + D[r * 4 + 1] * Go[4 + c] + D[r * 4 + 2] * Go[8 + c] + (c == 3 ? D[r * 4 + 3] : 0.0f);
-    }
-    se3_log<float>(p, G);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      st.dp[k] = dp[k];
-      st.p[k] = p[k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      st.dp[k] = dp[k];
-      p[k] = st.p[k] + dp[k];  // pose.cpp:118-123 additive update
-      st.p[k] = p[k];
-    }
-  }
-  se3_exp<float>(G, p);
-#pragma unroll
-  for (int k = 0; k < 12; ++k) st.G[k] = G[k];
-  // delta_p.lpNorm<1>() : Eigen's unrolled redux tree for 6 coefficients
-  const float nd = (fabsf(dp[0]) + (fabsf(dp[1]) + fabsf(dp[2]))) + (fabsf(dp[3]) + (fabsf(dp[4]) + fabsf(dp[5])));
-  st.normdp = nd;
-  if (st.it == 0) st.normdp_init = nd;
-  if (e.trace.rec != nullptr && prob == 0) {
-    const int c = *e.trace.count;
-    if (c < e.trace.capacity) {
-      ictr_trace_rec &r = e.trace.rec[c];
-      r.level = level;
-      r.iter = st.it;
-      for (int k = 0; k < 36; ++k) r.H[k] = st.H[k];
-      for (int k = 0; k < 6; ++k) {
-        r.b[k] = st.b[k];
-        r.dp[k] = dp[k];
-        r.p[k] = p[k];
-      }
-    }
-    *e.trace.count = c + 1;
-  }
-  st.it += 1;
-  st.total_iters += 1;
-  st.active = ((st.it < e.maxiter) & ((st.normdp / st.normdp_init) > e.ratio)) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- 8x8 patches: wave64 == patch, lane == pixel
@@ -420,6 +350,65 @@ __device__ __forceinline__ void ws_iterate(WaveSolver &s, float bi, const Engine
   s.total_iters += 1;
   s.active = ((s.it < e.maxiter) & ((s.normdp / s.normdp_init) > e.ratio)) ? 1 : 0;
   WS_MARK(3)
+}
+
+// ---- the solver state in the problem's device record (between the launches of the per-iteration form)
+// ProbState.LU holds the factors row-major, ProbState.piv the COMPOSED permutations (rowmap[6] | colmap[6]).
+__device__ __forceinline__ int h_unique_index(int lane) {  // lane l < 36 -> index of H[l/6][l%6] among the 21 sums
+  const int r = lane / 6, c = lane - 6 * r;
+  const int lo = r < c ? r : c, hi = r < c ? c : r;
+  return lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
+}
+__device__ __forceinline__ void ws_store_factor(const WaveSolver &s, ProbState &st, int lane) {
+  if (lane < 36) st.H[lane] = s.h;
+  if (lane < 6) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) st.LU[lane * 6 + j] = s.lu[j];
+    st.piv[lane] = s.rowmap;
+    st.piv[6 + lane] = s.colmap;
+  }
+  if (lane == 0) {
+    st.luinfo[0] = s.nonzero;
+    st.luinfo[1] = s.rank;
+  }
+}
+__device__ __forceinline__ void ws_load_factor(WaveSolver &s, const ProbState &st, int lane) {
+  const int r = lane < 6 ? lane : 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) s.lu[j] = st.LU[r * 6 + j];
+  s.diag = st.LU[r * 7];
+  s.rowmap = st.piv[r];
+  s.colmap = st.piv[6 + r];
+  s.h = lane < 36 ? st.H[lane] : 0.0f;
+  s.nonzero = st.luinfo[0];
+  s.rank = st.luinfo[1];
+}
+__device__ __forceinline__ void ws_load_state(WaveSolver &s, const ProbState &st, int lane, float *G) {
+  s.p = lane < 6 ? st.p[lane] : 0.0f;
+  s.b = s.dp = 0.0f;
+  s.normdp = st.normdp;
+  s.normdp_init = st.normdp_init;
+  s.it = st.it;
+  s.total_iters = st.total_iters;
+  s.active = st.active;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = st.G[k];
+}
+__device__ __forceinline__ void ws_store_state(const WaveSolver &s, ProbState &st, int lane, const float *G) {
+  if (lane < 6) {
+    st.p[lane] = s.p;
+    st.b[lane] = s.b;
+    st.dp[lane] = s.dp;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st.G[k] = G[k];
+    st.normdp = s.normdp;
+    st.normdp_init = s.normdp_init;
+    st.it = s.it;
+    st.active = s.active;
+    st.total_iters = s.total_iters;
+  }
 }
 
 }  // namespace ictr

@@ -23,6 +23,8 @@ void launch_pyr_pack(const float *, const float *, const float *, float *, size_
 void launch_stream_read(const float *, size_t, float *, hipStream_t);
 void launch_getpatch(const float *, const float *, const float *, const float *, int, int, int, int, float *, float *,
                      float *, hipStream_t);
+void launch_ncc(const float *, const float *, const float *, const float *, int, int, int, float, float, float, float,
+                float *, hipStream_t);
 void launch_project_generic(const float *, float *, float *, int, int, const float *, LevelCam, hipStream_t);
 void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
 void launch_ref_level(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
@@ -477,6 +479,31 @@ extern "C" int ictr_get_patch(const ictr_pyramid *pyr, int level, const float *m
 extern "C" int ictr_get_patch_grad(const ictr_pyramid *pyr, int level, const float *mids, int64_t K, int psz,
                                    int dopatchnorm, float *out, float *out_dx, float *out_dy) {
   return get_patch_impl(pyr, level, mids, K, psz, dopatchnorm, out, out_dx, out_dy, true);
+}
+
+// run_track_nposes.cpp:271-355: per-point patch correlation, computed on the device (k_ncc)
+extern "C" int ictr_ncc_score(const ictr_pyramid *pyr_back, const ictr_pyramid *pyr_ref, const ictr_pyramid *pyr_fwd,
+                              int level, const float *mids, int64_t K, int psz, float w_back, float w_fwd,
+                              float *out_corr) {
+  if (!pyr_back || !pyr_ref || !pyr_fwd || K < 0 || (K > 0 && (!mids || !out_corr)) || psz < 1 || psz > 64)
+    return fail(ICTR_ERR_INVALID, "ncc_score: bad arguments");
+  for (const ictr_pyramid *py : {pyr_back, pyr_ref, pyr_fwd})
+    if (level < 0 || level >= py->nlev || psz > py->pad || py->sw[level] != pyr_ref->sw[level] ||
+        py->w[level] != pyr_ref->w[level] || py->h[level] != pyr_ref->h[level])
+      return fail(ICTR_ERR_INVALID, "ncc_score: pyramids differ at level %d or padding < psz", level);
+  if (K == 0) return ICTR_OK;
+  if (int rc = need_device()) return rc;
+  float *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, sizeof(float) * 7 * K));
+  hipError_t e = hipMemcpy(d, mids, sizeof(float) * 6 * K, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_ncc(pyr_back->img[level], pyr_ref->img[level], pyr_fwd->img[level], d, (int)K, psz, pyr_ref->sw[level],
+               (float)pyr_ref->w[level], (float)pyr_ref->h[level], w_back, w_fwd, d + 6 * K, nullptr);
+    e = hipMemcpy(out_corr, d + 6 * K, sizeof(float) * K, hipMemcpyDeviceToHost);
+  }
+  hipFree(d);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "ncc_score failed: %s", hipGetErrorString(e));
+  return ICTR_OK;
 }
 
 // ---------------------------------------------------------------- PoseClass
@@ -1254,10 +1281,32 @@ extern "C" int ictr_odometer_trackpose(ictr_odometer *o, double *p_out) {
   if (!b->probs[0].pose_set) return fail(ICTR_ERR_STATE, "TrackPose before SetPose");
   if (!b->projected)
     if (int rc = ictr_batch_begin(b)) return rc;
-  if (int rc = enqueue_levels(b)) return rc;
+  // verbosity == 2: the reference prints |delta_p|_1 after every iteration (odometer.cpp:416-417); the device
+  // records every iteration (trace), printed below in the reference's format
+  const bool verbose = b->op->verbosity == 2, trace_was_on = b->trace_on;
+  if (verbose && !trace_was_on) {
+    b->trace_on = true;
+    HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));
+  }
+  int rc_enq = enqueue_levels(b);
+  b->trace_on = trace_was_on;
+  if (rc_enq) return rc_enq;
   // like the reference, a second TrackPose without SetPose continues from the current pose with the old
   // reference projections (device state persists)
   if (int rc = batch_fetch_state(b)) return rc;
+  if (verbose) {
+    int c = 0;
+    HIPCHK(hipMemcpy(&c, b->d_trace_count, sizeof(int), hipMemcpyDeviceToHost));
+    c = std::min(c, b->trace_cap);
+    std::vector<ictr_trace_rec> recs((size_t)std::max(c, 0));
+    if (c > 0) HIPCHK(hipMemcpy(recs.data(), b->d_trace, sizeof(ictr_trace_rec) * c, hipMemcpyDeviceToHost));
+    for (const ictr_trace_rec &r : recs) {
+      const float *d = r.dp;  // delta_p.lpNorm<1>() in Eigen's redux order, as on the device
+      const float nd = (fabsf(d[0]) + (fabsf(d[1]) + fabsf(d[2]))) + (fabsf(d[3]) + (fabsf(d[4]) + fabsf(d[5])));
+      printf("Sc%02i,It%02i: %g\n", r.level, r.iter, nd);
+    }
+    fflush(stdout);
+  }
   memcpy(o->pose->p, b->probs[0].p, sizeof(float) * 6);
   memcpy(o->pose->G, b->probs[0].G, sizeof(float) * 12);
   return ictr_pose_getpose_se3(o->pose, p_out);

@@ -216,90 +216,51 @@ __device__ __forceinline__ void reduce_partH(const EngineDev &e, int b, int nblk
   }
   __syncthreads();
 }
-// symmetric 6x6 from the 21 unique entries: st.H and the LDS copy that level_factor destroys
-__device__ __forceinline__ void expand_H(ProbState &st, const float *sH, float *sA) {
-  if (threadIdx.x < 36) {
-    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-    const int lo = r < c ? r : c, hi = r < c ? c : r;
-    const float v = sH[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-    st.H[threadIdx.x] = v;
-    sA[threadIdx.x] = v;
-  }
-  __syncthreads();
-}
-
 // defer_h: the P = 8 fast path accumulates H inside the level's FIRST iteration launch (k_iter8<.., WH = true>: it
 // streams Gx, Gy and the coefficients anyway), so the setup kernel is a pure gather/store kernel and this tail only
 // resets the loop state; the first k_iter_tail / k_iter_finish of the level reduces and factors H.
+// The factorisation and, per iteration, the solve / pose update / loop condition run on ONE wave in registers
+// (WaveSolver, ictr_devfn.h) instead of one thread on LDS arrays: 3-4 k cycles instead of ~14 k on the critical path
+// between two accumulate launches.
 __global__ __launch_bounds__(kBlock) void k_level_tail(EngineDev e, int nblk, int defer_h) {
   __shared__ double sRed[kBlock / 32][32];
   __shared__ float sH[32];
-  __shared__ float sA[36];
-  __shared__ int sI[16];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
   if (defer_h) {
     if (threadIdx.x == 0) level_reset(st, e);
     return;
   }
-  {
-    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    double s = 0.0;
-    const float *ph = e.partH + (size_t)b * nblk * kPartHStride + j;
-    if (j < kHUnique)
-      for (int k = sl; k < nblk; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
-    sRed[sl][j] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kHUnique) {
-    double s = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < kBlock / 32; ++sl) s += sRed[sl][threadIdx.x];
-    sH[threadIdx.x] = (float)s;
-  }
-  __syncthreads();
+  reduce_partH(e, b, nblk, sRed, sH);
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
   if (e.sharded) {
-    if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sH[threadIdx.x];
+    if (lane < kHUnique) e.red[(size_t)b * kRedStride + lane] = sH[lane];
   } else {
-    if (threadIdx.x < 36) {
-      const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-      const int lo = r < c ? r : c, hi = r < c ? c : r;
-      const float v = sH[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-      st.H[threadIdx.x] = v;
-      sA[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      level_factor(st, sA, sI);
-      level_reset(st, e);
-    }
+    WaveSolver S;
+    ws_factor(S, sH[h_unique_index(lane)], lane);
+    ws_store_factor(S, st, lane);
+    if (lane == 0) level_reset(st, e);
   }
 }
 
-// sharded mode: adopt the all-reduced H (red[b][0..20]) and reset the iteration state
-__global__ void k_level_finish(EngineDev e, int defer_h) {
-  __shared__ float sA[36];
-  __shared__ int sI[16];
+// sharded mode: adopt the all-reduced H (red[b][0..20]) and reset the iteration state (one wave per problem)
+__global__ __launch_bounds__(64) void k_level_finish(EngineDev e, int defer_h) {
   const int b = blockIdx.x;
+  const int lane = threadIdx.x;
   ProbState &st = e.st[b];
   if (defer_h) {
-    if (threadIdx.x == 0) level_reset(st, e);
+    if (lane == 0) level_reset(st, e);
     return;
   }
-  if (threadIdx.x < 36) {
-    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-    const int lo = r < c ? r : c, hi = r < c ? c : r;
-    const float v = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-    st.H[threadIdx.x] = v;
-    sA[threadIdx.x] = v;
-  }
-  __syncthreads();
+  const float a = e.red[(size_t)b * kRedStride + h_unique_index(lane)];
+  __builtin_amdgcn_wave_barrier();
   // leave the slot zeroed: the caller may all-reduce the whole buffer again before it is rewritten
-  if (threadIdx.x < kRedStride) e.red[(size_t)b * kRedStride + threadIdx.x] = 0.0f;
-  if (threadIdx.x == 0) {
-    level_factor(st, sA, sI);
-    level_reset(st, e);
-  }
+  if (lane < kRedStride) e.red[(size_t)b * kRedStride + lane] = 0.0f;
+  WaveSolver S;
+  ws_factor(S, a, lane);
+  ws_store_factor(S, st, lane);
+  if (lane == 0) level_reset(st, e);
 }
 
 // ---------------------------------------------------------------- steps 7-9a: one Gauss-Newton iteration (any patch size)
@@ -399,28 +360,17 @@ __global__ __launch_bounds__(kBlock) void k_iter(EngineDev e, LevelCam lc, int l
 }
 
 // One workgroup per problem: fixed-order f64 reduction of the b partials (32 slices x 8 components, then the
-// slices in order) and steps 9b-10 (solve, pose update, loop condition) -- or, when the points are sharded over
-// ranks, just the rank-local sum into red[] for the all-reduce.
+// slices in order) and steps 9b-10 (solve, pose update, loop condition) on wave 0 -- or, when the points are sharded
+// over ranks, just the rank-local sums into red[] for the all-reduce.
 __global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, int nblk, int first_h) {
   __shared__ double sRed[kBlock / 8][8];
-  __shared__ float sLU[64];
+  __shared__ double sRedH[kBlock / 32][32];
+  __shared__ float sH[32];
   const int b = blockIdx.x;
   ProbState &st = e.st[b];
   if (!st.active) return;
-  if (first_h) {  // deferred H: the launch before this one also wrote the H partials (workgroup-uniform branch)
-    __shared__ double sRedH[kBlock / 32][32];
-    __shared__ float sH[32];
-    __shared__ float sA[36];
-    __shared__ int sI[16];
-    reduce_partH(e, b, nblk, sRedH, sH);
-    if (e.sharded) {
-      if (threadIdx.x < kHUnique) e.red[(size_t)b * kRedStride + threadIdx.x] = sH[threadIdx.x];
-    } else {
-      expand_H(st, sH, sA);
-      if (threadIdx.x == 0) level_factor(st, sA, sI);
-      __syncthreads();  // st.LU / piv / luinfo are read back below
-    }
-  }
+  // deferred H: the launch before this one also wrote the H partials (workgroup-uniform branch)
+  if (first_h) reduce_partH(e, b, nblk, sRedH, sH);
   {
     const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
     double s = 0.0;
@@ -429,55 +379,55 @@ __global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, in
       for (int k = sl; k < nblk; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
     sRed[sl][j] = s;
   }
-  if (threadIdx.x >= 64 && threadIdx.x < 100) sLU[threadIdx.x - 64] = st.LU[threadIdx.x - 64];
-  if (threadIdx.x >= 128 && threadIdx.x < 140) reinterpret_cast<int *>(sLU)[48 + threadIdx.x - 128] = st.piv[threadIdx.x - 128];
-  if (threadIdx.x >= 140 && threadIdx.x < 142) reinterpret_cast<int *>(sLU)[60 + threadIdx.x - 140] = st.luinfo[threadIdx.x - 140];
   __syncthreads();
-  if (threadIdx.x < 6) {
-    double s = 0.0;
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  double bs = 0.0;
+  if (lane < 6) {
 #pragma unroll
-    for (int sl = 0; sl < kBlock / 8; ++sl) s += sRed[sl][threadIdx.x];
-    if (e.sharded)
-      e.red[(size_t)b * kRedStride + kHUnique + threadIdx.x] = (float)s;
-    else {
-      st.b[threadIdx.x] = (float)s;
-      sLU[36 + threadIdx.x] = (float)s;
-    }
+    for (int sl = 0; sl < kBlock / 8; ++sl) bs += sRed[sl][lane];
   }
-  __syncthreads();
-  if (threadIdx.x == 0 && !e.sharded) solve_and_update(st, e, level, b, sLU);
+  if (e.sharded) {
+    if (first_h && lane < kHUnique) e.red[(size_t)b * kRedStride + lane] = sH[lane];
+    if (lane < 6) e.red[(size_t)b * kRedStride + kHUnique + lane] = (float)bs;
+    return;
+  }
+  WaveSolver S;
+  float G[12];
+  ws_load_state(S, st, lane, G);
+  if (first_h) {
+    ws_factor(S, sH[h_unique_index(lane)], lane);
+    ws_store_factor(S, st, lane);
+  } else {
+    ws_load_factor(S, st, lane);
+  }
+  ws_iterate(S, (float)bs, e, level, b, lane, G);
+  ws_store_state(S, st, lane, G);
 }
 
 // sharded mode: steps 9b-10 on the all-reduced b (red[b][21..26]); every rank does the same arithmetic
-__global__ void k_iter_finish(EngineDev e, int level, int first_h) {
-  __shared__ float sLU[64][64];
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= e.B) return;
+// (one wave per problem)
+__global__ __launch_bounds__(64) void k_iter_finish(EngineDev e, int level, int first_h) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
   ProbState &st = e.st[b];
   if (!st.active) return;
-  float *ws = sLU[threadIdx.x];
-  if (first_h) {  // deferred H: adopt the all-reduced H (red[b][0..20]) and factor it
-    for (int r = 0; r < 6; ++r)
-      for (int c = 0; c < 6; ++c) {
-        const int lo = r < c ? r : c, hi = r < c ? c : r;
-        const float v = e.red[(size_t)b * kRedStride + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-        st.H[r * 6 + c] = v;
-        ws[r * 6 + c] = v;
-      }
-    for (int k = 0; k < kHUnique; ++k) e.red[(size_t)b * kRedStride + k] = 0.0f;
-    level_factor(st, ws, reinterpret_cast<int *>(ws) + 48);
+  WaveSolver S;
+  float G[12];
+  ws_load_state(S, st, lane, G);
+  float a = 0.0f, bi = 0.0f;
+  if (first_h) a = e.red[(size_t)b * kRedStride + h_unique_index(lane)];  // deferred H: adopt the all-reduced sums
+  if (lane < 6) bi = e.red[(size_t)b * kRedStride + kHUnique + lane];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < kRedStride && (first_h || lane >= kHUnique)) e.red[(size_t)b * kRedStride + lane] = 0.0f;
+  if (first_h) {
+    ws_factor(S, a, lane);
+    ws_store_factor(S, st, lane);
+  } else {
+    ws_load_factor(S, st, lane);
   }
-  for (int k = 0; k < 36; ++k) ws[k] = st.LU[k];
-  for (int k = 0; k < 12; ++k) reinterpret_cast<int *>(ws)[48 + k] = st.piv[k];
-  reinterpret_cast<int *>(ws)[60] = st.luinfo[0];
-  reinterpret_cast<int *>(ws)[61] = st.luinfo[1];
-  for (int k = 0; k < 6; ++k) {
-    const float v = e.red[(size_t)b * kRedStride + kHUnique + k];
-    st.b[k] = v;
-    ws[36 + k] = v;
-    e.red[(size_t)b * kRedStride + kHUnique + k] = 0.0f;
-  }
-  solve_and_update(st, e, level, b, ws);
+  ws_iterate(S, bi, e, level, b, lane, G);
+  ws_store_state(S, st, lane, G);
 }
 
 // ================================================================ P = 8 fast path (wave64 == one 8x8 patch)
@@ -1216,6 +1166,87 @@ __global__ __launch_bounds__(kBlock) void k_getpatch(const float *__restrict__ i
   }
 }
 
+// ---------------------------------------------------------------- patch NCC of run_track_nposes (run_track_nposes.cpp:271-355)
+// One wave per point: the mean-subtracted patches (util_getPatch with dopatchnorm forced on, :281) around the point's
+// position in the backward-most, the reference and the forward-most frame, each scaled to unit norm, and the two
+// correlations back-ref / ref-forward combined with the weights nBack^2 / nFwd^2. Only the K correlations leave the
+// device. NV = patch values per lane (psz^2 <= 64 NV). Validity tests are the reference's strict ones (:290,:297,:305).
+struct NccFrame {
+  const float *img;  // padded plane of the frame at the scoring level
+};
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_ncc(NccFrame fb, NccFrame fr, NccFrame ff, const float *__restrict__ mids,
+                                                int K, int P, int sw, float swo, float sho, float w_back, float w_fwd,
+                                                float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n = P * P;
+  for (int i = blockIdx.x * kWaves + wave; i < K; i += gridDim.x * kWaves) {
+    float pat[3][NV];
+    float nrm[3];
+    bool val[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const float mx = mids[(2 * f) * K + i], my = mids[(2 * f + 1) * K + i];
+      val[f] = (mx > 0.0f) & (my > 0.0f) & (mx < swo) & (my < sho);
+      const float *img = f == 0 ? fb.img : (f == 1 ? fr.img : ff.img);
+      const Taps tp = make_taps(val[f] ? mx : 1.0f, val[f] ? my : 1.0f, P / 2);
+      const int base = tp.row0 * sw + tp.col0;
+      float s = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int q = lane + 64 * v;
+        pat[f][v] = (q < n && val[f]) ? tap4(img, base + (q / P) * sw + (q % P), sw, tp) : 0.0f;
+        s += pat[f][v];
+      }
+      const float mean = wave_sum(s) / (float)n;  // utilities.cpp:111-112
+      float ss = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int q = lane + 64 * v;
+        pat[f][v] = q < n ? pat[f][v] - mean : 0.0f;
+        ss += pat[f][v] * pat[f][v];
+      }
+      nrm[f] = sqrtf(wave_sum(ss));  // patch.norm()
+    }
+    float dbr = 0.0f, drf = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float b = pat[0][v] / nrm[0], r = pat[1][v] / nrm[1], f = pat[2][v] / nrm[2];  // patch /= patch.norm()
+      if (lane + 64 * v < n) {
+        dbr += b * r;
+        drf += r * f;
+      }
+    }
+    dbr = wave_sum(dbr);
+    drf = wave_sum(drf);
+    if (lane == 0) {
+      float corr = -1.0f;
+      if (val[1]) {
+        const float cbr = val[0] ? fmaxf(0.0f, dbr) : -1.0f, w0 = val[0] ? w_back : 0.0f;
+        const float crf = val[2] ? fmaxf(0.0f, drf) : -1.0f, w1 = val[2] ? w_fwd : 0.0f;
+        corr = fmaxf(0.0f, (cbr * w0 + crf * w1) / (w0 + w1));  // std::max(0.0f, NaN) == 0.0f, as fmaxf
+      }
+      out[i] = corr;
+    }
+  }
+}
+void launch_ncc(const float *img_b, const float *img_r, const float *img_f, const float *mids, int K, int P, int sw,
+                float swo, float sho, float w_back, float w_fwd, float *out, hipStream_t s) {
+  int gx = (K + kWaves - 1) / kWaves;
+  gx = std::max(1, std::min(gx, kMaxGridX));
+  const NccFrame fb{img_b}, fr{img_r}, ff{img_f};
+  const int n = P * P;
+  if (n <= 64)
+    hipLaunchKernelGGL((k_ncc<1>), dim3(gx), dim3(kBlock), 0, s, fb, fr, ff, mids, K, P, sw, swo, sho, w_back, w_fwd, out);
+  else if (n <= 256)
+    hipLaunchKernelGGL((k_ncc<4>), dim3(gx), dim3(kBlock), 0, s, fb, fr, ff, mids, K, P, sw, swo, sho, w_back, w_fwd, out);
+  else if (n <= 1024)
+    hipLaunchKernelGGL((k_ncc<16>), dim3(gx), dim3(kBlock), 0, s, fb, fr, ff, mids, K, P, sw, swo, sho, w_back, w_fwd, out);
+  else
+    hipLaunchKernelGGL((k_ncc<64>), dim3(gx), dim3(kBlock), 0, s, fb, fr, ff, mids, K, P, sw, swo, sho, w_back, w_fwd, out);
+}
+
 // ---------------------------------------------------------------- pyramid (utilities.cpp:14-52)
 // level 0: copy the w x h image into the interior of the padded plane
 __global__ __launch_bounds__(kBlock) void k_pyr_copy(const float *__restrict__ src, float *dst, int w, int h, int pad,
@@ -1468,8 +1499,7 @@ void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, i
   launch_iter_tail(e, level, gridx, variant, gridx8, first, s);
 }
 void launch_iter_finish(const EngineDev &e, int level, int variant, int first, hipStream_t s) {
-  hipLaunchKernelGGL(k_iter_finish, dim3((e.B + 63) / 64), dim3(64), 0, s, e, level,
-                     (first && defer_h(e, variant)) ? 1 : 0);
+  hipLaunchKernelGGL(k_iter_finish, dim3(e.B), dim3(64), 0, s, e, level, (first && defer_h(e, variant)) ? 1 : 0);
 }
 
 }  // namespace ictr

@@ -22,7 +22,7 @@ import sys
 import numpy as np
 
 from . import io_formats as iof
-from .tracker import CamClass, TrackBatch, optparam, util_constructpyramide, util_getPatch
+from .tracker import CamClass, TrackBatch, ncc_score, optparam, util_constructpyramide
 
 __all__ = ["run", "main"]
 
@@ -81,34 +81,22 @@ def _track_samples(cam, op, pyrs, sample_ids, inp, out_pose, pts2d):
 
 
 def _ncc(cam, op_ncc, pyrs, inp, pts2d, nsamples):
-    """Patch correlation of every point of every sample (run_track_nposes.cpp:271-355), patches fetched on the GPU."""
+    """Patch correlation of every point of every sample (run_track_nposes.cpp:271-355): one device launch for all
+    samples (k_ncc: fetch, zero-mean, unit norm, the two dot products and the weighting per point in one wave); only
+    the correlations come back."""
     nback, nfwd = inp["fbframes"]
-    lv = op_ncc.lv_l
-    swo, sho = cam.getswo(lv), cam.getsho(lv)
-    frames = (0, nback, len(pyrs) - 1)  # backward-most, reference, forward-most frame
-    out = []
-    for sid in range(nsamples):
-        pats, vals = [], []
-        for which in range(3):
-            mids = np.asarray(pts2d[sid][which], np.float32).reshape(-1, 2)
-            ok = (mids[:, 0] > 0) & (mids[:, 1] > 0) & (mids[:, 0] < swo) & (mids[:, 1] < sho)  # strict, :290,:297,:305
-            p = np.zeros((len(mids), op_ncc.novals), np.float32)
-            if ok.any():
-                p[ok] = util_getPatch(pyrs[frames[which]], lv, mids[ok], op_ncc)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                p = p / np.sqrt(np.sum(p * p, axis=1, dtype=np.float32))[:, None]
-            pats.append(p)
-            vals.append(ok)
-        pb, pr, pf = pats
-        bv, rv, fv = vals
-        w0 = np.where(bv, np.float32(nback * nback), np.float32(0))
-        w1 = np.where(fv, np.float32(nfwd * nfwd), np.float32(0))
-        cbr = np.where(bv, np.maximum(np.float32(0), np.nan_to_num(np.sum(pb * pr, 1, dtype=np.float32))), np.float32(-1))
-        crf = np.where(fv, np.maximum(np.float32(0), np.nan_to_num(np.sum(pr * pf, 1, dtype=np.float32))), np.float32(-1))
-        with np.errstate(invalid="ignore", divide="ignore"):
-            c = (cbr * w0 + crf * w1) / (w0 + w1)
-        c = np.where(np.isnan(c), np.float32(0), np.maximum(np.float32(0), c))  # std::max(0.0f, NaN) == 0.0f
-        out.append(np.where(rv, c, np.float32(-1)).astype(np.float64))
+    if nsamples == 0:
+        return []
+    counts = [len(pts2d[sid][1]) for sid in range(nsamples)]
+    back = np.concatenate([np.asarray(pts2d[sid][0], np.float32).reshape(-1, 2) for sid in range(nsamples)], 0)
+    refe = np.concatenate([np.asarray(pts2d[sid][1], np.float32).reshape(-1, 2) for sid in range(nsamples)], 0)
+    forw = np.concatenate([np.asarray(pts2d[sid][2], np.float32).reshape(-1, 2) for sid in range(nsamples)], 0)
+    corr = ncc_score(pyrs[0], pyrs[nback], pyrs[len(pyrs) - 1], op_ncc.lv_l, back, refe, forw, op_ncc.psz,
+                     nback * nback, nfwd * nfwd)  # backward-most, reference, forward-most frame; weights :321,:332
+    out, lo = [], 0
+    for c in counts:
+        out.append(corr[lo:lo + c].astype(np.float64))
+        lo += c
     return out
 
 

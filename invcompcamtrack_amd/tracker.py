@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import OptParam, TraceRec, check, dp, f32c, f64c, fp
 
 __all__ = ["optparam", "CamClass", "PoseClass", "OdometerClass", "Pyramid", "TrackBatch",
-           "util_constructpyramide", "util_getPatch", "util_getPatch_grad", "util_SE3_coeff_to_group",
+           "util_constructpyramide", "util_getPatch", "util_getPatch_grad", "ncc_score", "util_SE3_coeff_to_group",
            "util_SE3_group_to_coeff", "solve6", "device_count"]
 
 
@@ -135,6 +135,18 @@ def util_getPatch_grad(pyr, level, mids, op):
     check(_lib.load().ictr_get_patch_grad(pyr._h, level, fp(soa), K, op.psz, int(op.dopatchnorm), fp(o[0]), fp(o[1]),
                                           fp(o[2])))
     return tuple(o)
+
+
+def ncc_score(pyr_back, pyr_ref, pyr_fwd, level, mids_back, mids_ref, mids_fwd, psz, w_back, w_fwd):
+    """Per-point patch correlation of run_track_nposes.cpp:271-355, on the device (ictr_ncc_score).
+    mids_*: (K,2) positions at `level` in the backward-most / reference / forward-most frame -> (K,) float32."""
+    mb, mr, mf = (np.atleast_2d(np.asarray(m, np.float32)) for m in (mids_back, mids_ref, mids_fwd))
+    K = mr.shape[0]
+    soa = np.ascontiguousarray(np.concatenate([mb.T, mr.T, mf.T], 0), np.float32)  # xb yb xr yr xf yf, K each
+    out = np.empty(K, np.float32)
+    check(_lib.load().ictr_ncc_score(pyr_back._h, pyr_ref._h, pyr_fwd._h, level, fp(soa), K, psz, float(w_back),
+                                     float(w_fwd), fp(out)))
+    return out
 
 
 def util_SE3_coeff_to_group(p):

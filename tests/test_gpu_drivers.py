@@ -145,3 +145,86 @@ def test_run_track_nposes_matches_serial_oracle(oracle, tmp_path, dopatchnorm):
         assert corr_g[sid].shape == (len(inl[sid]),)
         assert np.abs(corr_g[sid] - corr_o[sid]).max() <= 2e-3  # printed with 3 significant digits
         assert corr_g[sid].min() >= 0.0 and np.median(corr_g[sid]) > 0.9
+
+
+@pytest.mark.parametrize("psz", [8, 4, 12])
+def test_ncc_score_on_device_matches_numpy_restatement(oracle, psz):
+    """ictr_ncc_score (run_track_nposes.cpp:271-355 in one kernel): valid points against a NumPy restatement on the
+    oracle's patches, and every edge of the reference's logic: reference position outside -> -1; one neighbour frame
+    outside -> that term dropped; both outside -> 0 (0/0 -> NaN -> std::max(0,NaN) = 0); flat patch -> 0."""
+    sc = scene(256, 224, 80, seed=9, margin=14.0)
+    lv, pad = 0, psz   # the reference pads by psz (run_track_nposes.cpp:180); the tap offsets assume it
+    flat = np.full_like(sc["img_a"], 77.0)
+    imgs = [sc["img_a"], sc["img_b"], (0.5 * (sc["img_a"] + sc["img_b"])).astype(np.float32), flat]
+    gp = [ic.Pyramid(im, 1, pad) for im in imgs]
+    op = oracle.make_op(1, 0, psz, 1, 0.0, 0, 1, 80)   # dopatchnorm on, like run_track_nposes.cpp:281
+    opl = [oracle.Pyramid(im, 1, pad) for im in imgs]
+    rng = np.random.default_rng(4)
+    K = 64
+    mr = np.stack([rng.uniform(20, 236, K), rng.uniform(20, 204, K)], 1).astype(np.float32)
+    mb = (mr + rng.normal(0, 0.4, (K, 2))).astype(np.float32)
+    mf = (mr + rng.normal(0, 0.4, (K, 2))).astype(np.float32)
+    mr[0] = (-3.0, 50.0)                    # reference outside -> -1
+    mb[1] = (300.0, 50.0)                   # back outside: only the ref-forward term
+    mf[2] = (50.0, 0.0)                     # forward on the border (strict test) -> dropped
+    mb[3], mf[3] = (-1.0, 5.0), (5.0, 500.0)   # both neighbours outside -> 0
+    got = ic.ncc_score(gp[0], gp[1], gp[2], lv, mb, mr, mf, psz, 4.0, 9.0)
+    swo, sho = 256.0, 224.0
+    want = np.full(K, -1.0)
+    for i in range(K):
+        ok = [bool((m[i, 0] > 0) and (m[i, 1] > 0) and (m[i, 0] < swo) and (m[i, 1] < sho)) for m in (mb, mr, mf)]
+        if not ok[1]:
+            continue
+        pats = []
+        for k, m in enumerate((mb, mr, mf)):
+            if ok[k]:
+                pt = oracle.getpatch(opl[k].img[lv], m[i], op).astype(np.float64)
+                pats.append(pt / np.sqrt(np.sum(pt * pt)))
+            else:
+                pats.append(None)
+        w0, w1 = (4.0 if ok[0] else 0.0), (9.0 if ok[2] else 0.0)
+        cbr = max(0.0, float(np.sum(pats[0] * pats[1]))) if ok[0] else -1.0
+        crf = max(0.0, float(np.sum(pats[1] * pats[2]))) if ok[2] else -1.0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c = np.float64(cbr * w0 + crf * w1) / np.float64(w0 + w1)
+        want[i] = 0.0 if np.isnan(c) else max(0.0, c)
+    assert want[0] == -1.0 and want[3] == 0.0 and np.sum(want > 0.5) > 40
+    assert np.abs(got - want).max() <= 2e-5, np.abs(got - want).argmax()
+    # frames without texture at integer positions (bilinear weights 0,0,0,1: the patch is exactly constant): zero
+    # norm -> NaN -> std::max(0, NaN) = 0
+    mi = np.round(mr[4:8])
+    got_flat = ic.ncc_score(gp[3], gp[1], gp[3], lv, mi, mi, mi, psz, 4.0, 9.0)
+    assert np.array_equal(got_flat, np.zeros(4, np.float32))
+
+
+def test_verbosity_2_prints_the_reference_iteration_log(oracle, capfd):
+    """odometer.cpp:416-417: printf("Sc%02i,It%02i: %g\\n", sl, it, normdp) after every iteration when verbosity == 2."""
+    sc = scene(256, 224, 150, seed=12, margin=12.0)
+    for variant in (0, 8192):   # one-launch tracker and per-iteration launches
+        op = ic.optparam(2, 0, 8, 4, 0.0, 0, 0, 150, 2)
+        cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+        pose = ic.PoseClass(cam, op)
+        odo = ic.OdometerClass(pose, op)
+        odo.set_variant(variant)
+        odo.enable_trace()
+        odo.Set3Dpoints(sc["pts3d"].copy())
+        odo.SetPose(sc["p_a"], ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8))
+        capfd.readouterr()
+        odo.TrackPose()
+        out = capfd.readouterr().out.strip().splitlines()
+        tr = odo.trace()
+        assert len(out) == 12 == len(tr)
+        for line, r in zip(out, tr):
+            nd = np.float32(0)
+            d = np.abs(r["dp"]).astype(np.float32)
+            nd = (d[0] + (d[1] + d[2])) + (d[3] + (d[4] + d[5]))
+            assert line == "Sc%02i,It%02i: %g" % (r["level"], r["iter"], nd), (line, r["level"], r["iter"])
+        assert out[0].startswith("Sc02,It00: ") and out[-1].startswith("Sc00,It03: ")
+    # verbosity 0 prints nothing
+    op0 = ic.optparam(2, 0, 8, 2, 0.0, 0, 0, 150, 0)
+    odo0 = ic.OdometerClass(ic.PoseClass(cam, op0), op0)
+    odo0.Set3Dpoints(sc["pts3d"].copy())
+    odo0.SetPose(sc["p_a"], ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8))
+    capfd.readouterr()
+    odo0.TrackPose()
+    assert capfd.readouterr().out == ""
