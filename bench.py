@@ -66,6 +66,10 @@ def parse():
                     help="sharded mode: force this many groups of pairs per rank (0 = choose by timing)")
     ap.add_argument("--tune-groups", action="store_true",
                     help="sharded mode: also time the two-group candidates (their launches overlap on two streams)")
+    ap.add_argument("--rccl-direct", action="store_true",
+                    help="sharded mode: also try the library's own in-stream RCCL communicator (dist.RcclDirect)")
+    ap.add_argument("--p2p", action="store_true",
+                    help="sharded mode: also try the one-shot peer-to-peer exchange of the 27-float records (dist.P2PDirect)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (sharded phases + collectives) with a world of 1 (testing)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
@@ -74,6 +78,9 @@ def parse():
     ap.add_argument("--secondary-seconds", type=float, default=1.0, help="time budget of each secondary record")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="ranks only join a gloo group and all-reduce one number (CPU test of the --gpus N launcher)")
+    ap.add_argument("--rehearse-p2p", action="store_true",
+                    help="N>1 rehearsal on ONE GPU: all ranks use cuda:0, gloo group for the set-up, the 27*B floats "
+                         "exchanged by the one-shot peer-to-peer kernel through hipIpc-mapped mailboxes (not a benchmark)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on ONE GPU: all ranks use cuda:0 and the 27*B floats are all-reduced through "
                          "host memory with gloo (same kernels, same phase sequence; numbers are not a benchmark)")
@@ -233,7 +240,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    if world > 1 and args.rehearse_gloo:
+    if args.rehearse_p2p:
+        args.p2p = True
+    one_gpu = args.rehearse_gloo or args.rehearse_p2p   # every rank on cuda:0, host-side group = gloo
+    if world > 1 and one_gpu:
         import torch.distributed as dist
         local_rank = 0
         torch.cuda.set_device(0)
@@ -369,22 +379,30 @@ def main():
         # group's collective (link latency) overlaps the other group's kernels. "torch" = torch.distributed on its
         # own stream, with one group (collective exposed) or two (hidden behind the other group's compute).
         two = (B % 2 == 0 and B >= 2)
+        # "torch" = torch.distributed (RCCL on its own stream): the default, the only path that has run on real
+        # multi-GPU nodes. --rccl-direct adds the in-stream communicator as a candidate (it joins only if its
+        # lock-step set-up and self-test succeed on every rank), --p2p the one-shot peer-to-peer exchange.
+        modes = ["torch"] + (["direct"] if args.rccl_direct else []) + (["p2p"] if args.p2p else [])
         if args.groups:
-            cands = [("direct", args.groups), ("torch", args.groups)]
+            cands = [(m, args.groups) for m in modes]
         else:
             # default: one group, like the single-GPU default (kernels never overlap, clean per-launch durations);
-            # --groups 0 adds the two-group candidates (overlapping launches, higher throughput)
-            cands = [("direct", 1), ("torch", 1)]
-            if args.groups == 0 and args.tune_groups and two:
-                cands += [("direct", 2), ("torch", 2)]
+            # --tune-groups adds the two-group candidates (overlapping launches, higher throughput)
+            cands = [(m, 1) for m in modes]
+            if args.tune_groups and two:
+                cands += [(m, 2) for m in modes if m != "p2p"]
         if args.rehearse_gloo:
             cands = [c for c in cands if c[0] == "torch"]
+        if args.rehearse_p2p:
+            cands = [c for c in cands if c[0] == "p2p"]
         built, tuning = {}, {}
         for mode, g in cands:
             engines = inp["make_engines"](g, split=True)
-            tracker = ShardedTracker(engines, staged=args.rehearse_gloo, direct=(mode == "direct"))
-            ok = torch.tensor([1.0 if (mode == "torch" or tracker.direct is not None) else 0.0], dtype=torch.float64,
-                              device="cpu" if args.rehearse_gloo else "cuda")
+            tracker = ShardedTracker(engines, staged=args.rehearse_gloo, direct=(mode == "direct"), p2p=(mode == "p2p"))
+            have = (mode == "torch" or (mode == "direct" and tracker.direct is not None)
+                    or (mode == "p2p" and tracker.p2p is not None))
+            ok = torch.tensor([1.0 if have else 0.0], dtype=torch.float64,
+                              device="cpu" if one_gpu else "cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # a path is a candidate only if every rank has it
             if float(ok.item()) < 1.0:
                 continue
@@ -397,7 +415,7 @@ def main():
                 run(2, False)
                 barrier()
                 t_g = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64,
-                                   device="cpu" if args.rehearse_gloo else "cuda")
+                                   device="cpu" if one_gpu else "cuda")
                 dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
                 tuning[key] = float(t_g.item()) / 2 * 1e3
         best = min(tuning, key=tuning.get) if tuning else next(iter(built))
@@ -424,7 +442,7 @@ def main():
         print("[bench] host ms per step: " + ", ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in host_t.items()),
               file=sys.stderr, flush=True)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -457,6 +475,7 @@ def main():
                        "host_pipeline": ("2 engines alternate, host one step ahead" if (len(engines) == 2 and tracker is None)
                                          else "none"),
                        "collective": ((("RCCL in-stream (own communicator)" if tracker.direct is not None
+                                        else "one-shot P2P mailbox exchange" if getattr(tracker, "p2p", None) is not None
                                         else "torch.distributed (own stream)")
                                        + f", {len(engines)} group(s) of pairs per rank; tuning ms/step: {tuning}")
                                       if sharded else "n/a"),

@@ -256,6 +256,20 @@ int ictr_batch_level_finish(ictr_batch *b, int level);      /* adopt (reduced) H
 int ictr_batch_iter_accumulate(ictr_batch *b, int level);   /* steps 7-9a -> local b in red[] */
 int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on the (reduced) b */
 
+/* ---- one-shot peer-to-peer all-reduce of the reduction buffer (latency-optimal on point-to-point xGMI) ----
+ * Each rank stores its nproblems*27 floats straight into a mailbox slot in every peer's device memory (mapped with
+ * hipIpc) and adds the world slots of its own mailbox in rank order: one hop instead of a ring's 2(N-1), one small
+ * kernel on the compute stream, identical bits on every rank. Set-up: create -> exchange the local handles through any
+ * host channel (torch.distributed all_gather) -> connect. See csrc/ictr_p2p.hip for the protocol. */
+typedef struct ictr_p2p ictr_p2p;
+int ictr_p2p_create(ictr_p2p **out, int rank, int world, int64_t count /* floats per exchange */);
+int ictr_p2p_handle_bytes(void);                                  /* sizeof(hipIpcMemHandle_t) */
+int ictr_p2p_local_handle(ictr_p2p *p, void *handle_out);          /* this rank's mailbox handle */
+int ictr_p2p_connect(ictr_p2p *p, const void *all_handles);        /* world handles, rank order */
+int ictr_p2p_allreduce(ictr_p2p *p, float *dev_buf, int64_t count, void *hip_stream); /* in place, asynchronous */
+int ictr_p2p_error(ictr_p2p *p); /* 1 if an exchange timed out (a peer never arrived); synchronises the device */
+void ictr_p2p_destroy(ictr_p2p *p);
+
 /* ------------------------------------------------------------------ flow producer for the misc_src/run_*OF* drivers
  * Those drivers shell out to an external optical-flow binary that is not in the reference repository
  * (misc_src/run_test_OF_track.py:90-108). ictr_patchflow is the in-tree replacement: K independent psz x psz patches

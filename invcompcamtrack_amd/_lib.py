@@ -128,6 +128,13 @@ SIGNATURES = {
     "ictr_batch_level_finish": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_accumulate": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_finish": (C.c_int, [VP, C.c_int]),
+    "ictr_p2p_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, I64]),
+    "ictr_p2p_handle_bytes": (C.c_int, []),
+    "ictr_p2p_local_handle": (C.c_int, [VP, VP]),
+    "ictr_p2p_connect": (C.c_int, [VP, VP]),
+    "ictr_p2p_allreduce": (C.c_int, [VP, VP, I64, VP]),
+    "ictr_p2p_error": (C.c_int, [VP]),
+    "ictr_p2p_destroy": (None, [VP]),
     "ictr_patchflow": (C.c_int, [VP, VP, FP, I64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, IP, IP]),
     "ictr_patchflow_last_kernel_ms": (C.c_float, []),
     "ictr_icgn_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, IP,

@@ -1041,14 +1041,15 @@ static bool use_track1(const ictr_batch *b) {
   return (int64_t)b->maxpts * b->n <= (int64_t)limit * 64;
 }
 static int track1_waves(const ictr_batch *b) {
+  // Always the same workgroup shape: which wave owns which patch -- and with it the order of every sum -- then depends
+  // on the problem's own point count only, so a problem gives the same bits whatever else shares its launch
+  // (run_track_nposes: any split of the pose samples over batches or ranks writes the same file).
   static const int forced = [] {
     const char *s = getenv("ICTR_TRACK1_WAVES");
     return s ? atoi(s) : 0;
   }();
-  if (forced > 0) return forced;
-  const int ppw = (b->n <= 64 && 64 % b->n == 0) ? 64 / b->n : 1;
-  const int groups = (b->maxpts + ppw - 1) / ppw;
-  return std::min(8, std::max(4, (groups + 3) / 4));
+  (void)b;
+  return forced > 0 ? forced : 8;
 }
 
 // split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket

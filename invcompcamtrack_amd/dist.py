@@ -33,19 +33,42 @@ def shard_slices(n_points: int, world: int):
     return out
 
 
+def _coll_device(dist, group=None):
+    """Device a tensor must live on to go through this group's collectives: RCCL ("nccl") only takes GPU tensors."""
+    try:
+        return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    except Exception:
+        return "cpu"
+
+
 def global_norm(pts_local, group=None, dist=None):
     """Mean and mean squared radius (odometer.cpp:193-214) of the union of all ranks' points.
-    pts_local: (3, n_local) float64. Two tiny all-reduces (f64)."""
+    pts_local: (3, n_local) float64. Two tiny all-reduces (f64), on the backend's device."""
     import torch
     if dist is None:
         import torch.distributed as dist
+    dev = _coll_device(dist, group)
     acc = torch.tensor([pts_local[0].sum(), pts_local[1].sum(), pts_local[2].sum(), float(pts_local.shape[1])],
-                       dtype=torch.float64)
+                       dtype=torch.float64, device=dev)
     dist.all_reduce(acc, group=group)
+    acc = acc.cpu()
     mean = (acc[:3] / acc[3]).numpy().copy()
-    var = torch.tensor([float(((pts_local - mean[:, None]) ** 2).sum())], dtype=torch.float64)
+    var = torch.tensor([float(((pts_local - mean[:, None]) ** 2).sum())], dtype=torch.float64, device=dev)
     dist.all_reduce(var, group=group)
-    return mean, float(var[0] / acc[3])
+    return mean, float(var.cpu()[0] / acc[3])
+
+
+def sharded_set3dpoints(batch, problem, pts_local, group=None, dist=None):
+    """Set3Dpoints for a rank's shard of a problem's points when ``donorm`` is on: the cloud normalisation of
+    odometer.cpp:193-214 must use the mean / mean squared radius of ALL ranks' points, so they are all-reduced first
+    (global_norm) and handed to the engine (TrackBatch.Set3Dpoints_norm). pts_local: (3, n_local) float64,
+    C-contiguous, normalised in place like the reference does with its caller's array. Returns (mean, varval)."""
+    if not batch.op.donorm:
+        batch.Set3Dpoints(problem, pts_local)
+        return np.zeros(3), 0.0
+    mean, var = global_norm(pts_local, group=group, dist=dist)
+    batch.Set3Dpoints_norm(problem, pts_local, mean, var)
+    return mean, var
 
 
 def run_sharded_levels(engine, op, allreduce):
@@ -104,50 +127,99 @@ class _Done:
         return None
 
 
+def _agree(torch, dist, group, ok):
+    """MIN all-reduce of a success flag: every rank learns whether EVERY rank succeeded. All ranks must call it at
+    the same point whatever happened to them locally, so that the group's collectives stay matched."""
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=_coll_device(dist, group))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return float(flag.cpu()[0]) >= 1.0
+
+
 class RcclDirect:
     """RCCL called directly (ctypes on the librccl.so PyTorch ships) with its own communicator, so that the all-reduce
     is enqueued ON THE COMPUTE STREAM between the tail and the finish kernels. torch.distributed runs collectives on
     its own stream and synchronises with events in both directions; measured on MI355X that costs ~24 us of idle
     compute stream per collective even when there is nothing to wait for (profiles/r01_notes.md) -- per Gauss-Newton
-    iteration. The unique id is created on rank 0 and broadcast through the existing torch.distributed group.
-    Any failure while setting up raises, and ShardedTracker falls back to torch.distributed."""
+    iteration. Opt-in (ShardedTracker(direct=True) / ICTR_RCCL_DIRECT=1): it has only ever run with a world of one.
+
+    Setting up is a fixed sequence of collectives on the torch group that EVERY rank executes whatever fails locally
+    (a rank that raised early would leave the others blocked in a broadcast):
+      1. rank 0 broadcasts 129 bytes: a status byte + the unique id (status 0: it could not create one); all ranks
+         agree (MIN all-reduce) that each of them holds the id and has the library;
+      2. every rank calls ncclCommInitRank, then all ranks agree;
+      3. every rank runs the self-test (sum of ones == world), then all ranks agree again.
+    After any disagreement every rank destroys what it built and ``ok`` is False on every rank."""
 
     def __init__(self, torch, dist, group=None):
         import ctypes as C
         import os
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self._C, self._lib = C, C.CDLL(path)
-
-        class UniqueId(C.Structure):
-            _fields_ = [("internal", C.c_char * 128)]
-
-        L = self._lib
-        L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(UniqueId)], C.c_int
-        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-        L.ncclCommInitRank.restype = C.c_int
-        L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.ncclAllReduce.restype = C.c_int
-        L.ncclCommDestroy.argtypes, L.ncclCommDestroy.restype = [C.c_void_p], C.c_int
+        self._C, self._lib, self._comm, self.ok, self.why = C, None, None, False, ""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        uid = UniqueId()
-        if rank == 0 and L.ncclGetUniqueId(C.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
-        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-        raw = C.string_at(C.addressof(uid), 128)  # the raw 128 bytes (a c_char array read as bytes stops at a NUL)
-        t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
-        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        C.memmove(C.addressof(uid), bytes(t.cpu().tolist()), 128)
-        self._comm = C.c_void_p()
-        rc = L.ncclCommInitRank(C.byref(self._comm), world, uid, rank)
-        if rc != 0 or not self._comm:
-            raise RuntimeError(f"ncclCommInitRank failed ({rc})")
         self.world = world
-        # self-test before anything relies on it: the sum of ones over the ranks must be the world size
-        probe = torch.ones(4, dtype=torch.float32, device="cuda")
-        self.all_reduce_sum_f32(probe.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        if not bool((probe == float(world)).all().item()):
-            raise RuntimeError(f"direct all-reduce self-test failed: {probe.tolist()} != {world}")
+        dev = _coll_device(dist, group)
+        UniqueId = None
+        local_ok = True
+        try:
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            L = self._lib = C.CDLL(path)
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+
+            L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(UniqueId)], C.c_int
+            L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            L.ncclCommInitRank.restype = C.c_int
+            L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            L.ncclAllReduce.restype = C.c_int
+            L.ncclCommDestroy.argtypes, L.ncclCommDestroy.restype = [C.c_void_p], C.c_int
+        except Exception as exc:  # the library is missing on this rank: still walk through the collectives below
+            local_ok, self.why = False, f"librccl.so: {exc!r}"
+        # 1. status byte + unique id, always broadcast by rank 0
+        msg = bytearray(129)
+        uid = UniqueId() if UniqueId is not None else None
+        if rank == 0 and local_ok:
+            if self._lib.ncclGetUniqueId(C.byref(uid)) == 0:
+                msg[0] = 1
+                msg[1:] = C.string_at(C.addressof(uid), 128)  # raw bytes (a c_char array read as bytes stops at a NUL)
+            else:
+                self.why = "ncclGetUniqueId failed"
+        t = torch.tensor(list(msg), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(t.cpu().tolist())
+        have_uid = raw[0] == 1
+        # ncclCommInitRank is itself a rendezvous of all ranks: only enter it when every rank can
+        if not _agree(torch, dist, group, local_ok and have_uid):
+            self.why = self.why or ("rank 0 has no unique id" if not have_uid else "another rank cannot load RCCL")
+            return
+        # 2. communicator
+        if local_ok and have_uid:
+            try:
+                C.memmove(C.addressof(uid), raw[1:], 128)
+                comm = C.c_void_p()
+                rc = self._lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+                if rc != 0 or not comm:
+                    raise RuntimeError(f"ncclCommInitRank failed ({rc})")
+                self._comm = comm
+            except Exception as exc:
+                local_ok, self.why = False, repr(exc)
+        if not _agree(torch, dist, group, local_ok and have_uid):
+            self.why = self.why or "another rank could not set up its communicator"
+            self.close()
+            return
+        # 3. self-test before anything relies on it: the sum of ones over the ranks must be the world size
+        try:
+            probe = torch.ones(4, dtype=torch.float32, device="cuda")
+            self.all_reduce_sum_f32(probe.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            if not bool((probe == float(world)).all().item()):
+                raise RuntimeError(f"self-test: {probe.tolist()} != {world}")
+        except Exception as exc:
+            local_ok, self.why = False, repr(exc)
+        if not _agree(torch, dist, group, local_ok):
+            self.why = self.why or "another rank failed the self-test"
+            self.close()
+            return
+        self.ok = True
 
     def all_reduce_sum_f32(self, dev_ptr, count, stream):
         rc = self._lib.ncclAllReduce(dev_ptr, dev_ptr, count, 7, 0, self._comm, stream)  # ncclFloat32, ncclSum
@@ -156,17 +228,108 @@ class RcclDirect:
 
     def close(self):
         if getattr(self, "_comm", None):
-            self._lib.ncclCommDestroy(self._comm)
-            self._comm = None
+            try:
+                self._lib.ncclCommDestroy(self._comm)
+            finally:
+                self._comm = None
+        self.ok = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class P2PDirect:
+    """One-shot peer-to-peer all-reduce (csrc/ictr_p2p.hip): every rank writes its records into a mailbox slot in every
+    peer's memory (hipIpc-mapped) and sums its own mailbox in rank order -- one hop over the point-to-point xGMI links
+    instead of a ring's 2(N-1), one small kernel on the compute stream, identical bits on every rank. The mailbox
+    handles travel through the existing torch.distributed group. Like RcclDirect the set-up is a fixed sequence of
+    collectives that every rank executes whatever fails locally, and ends with the same verdict (``ok``) everywhere:
+    create + all_gather of the handles -> agree -> connect (hipIpcOpenMemHandle) -> agree -> self-test -> agree."""
+
+    def __init__(self, torch, dist, group, count):
+        import ctypes as C
+        from . import _lib
+        self._C, self._h, self.ok, self.why = C, None, False, ""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.world, self.count = world, int(count)
+        dev = _coll_device(dist, group)
+        local_ok = True
+        hb = 64
+        try:
+            self._L = _lib.load()
+            hb = self._L.ictr_p2p_handle_bytes()
+            h = C.c_void_p()
+            _lib.check(self._L.ictr_p2p_create(C.byref(h), rank, world, self.count))
+            self._h = h
+            mine = (C.c_char * hb)()
+            _lib.check(self._L.ictr_p2p_local_handle(self._h, C.cast(mine, C.c_void_p)))
+            mine = bytes(mine)
+        except Exception as exc:
+            local_ok, self.why, mine = False, repr(exc), bytes(hb)
+        t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t, group=group)
+        if not _agree(torch, dist, group, local_ok):
+            self.why = self.why or "another rank could not create its mailbox"
+            self.close()
+            return
+        try:
+            allh = b"".join(bytes(g.cpu().tolist()) for g in gathered)
+            buf = C.create_string_buffer(allh, len(allh))
+            _lib.check(self._L.ictr_p2p_connect(self._h, C.cast(buf, C.c_void_p)))
+        except Exception as exc:
+            local_ok, self.why = False, repr(exc)
+        if not _agree(torch, dist, group, local_ok):
+            self.why = self.why or "another rank could not map the peers' mailboxes"
+            self.close()
+            return
+        try:  # self-test: the sum of (rank + 1) over the ranks
+            probe = torch.full((4,), float(rank + 1), dtype=torch.float32, device="cuda")
+            self.all_reduce_sum_f32(probe.data_ptr(), 4, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want = float(world * (world + 1) // 2)
+            if self._L.ictr_p2p_error(self._h) or not bool((probe == want).all().item()):
+                raise RuntimeError(f"self-test: {probe.tolist()} != {want}")
+        except Exception as exc:
+            local_ok, self.why = False, repr(exc)
+        if not _agree(torch, dist, group, local_ok):
+            self.why = self.why or "another rank failed the self-test"
+            self.close()
+            return
+        self.ok = True
+
+    def all_reduce_sum_f32(self, dev_ptr, count, stream):
+        from . import _lib
+        _lib.check(self._L.ictr_p2p_allreduce(self._h, self._C.c_void_p(dev_ptr), int(count), self._C.c_void_p(stream)))
+
+    def error(self):
+        return bool(self._L.ictr_p2p_error(self._h)) if self._h else True
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ictr_p2p_destroy(self._h)
+            self._h = None
+        self.ok = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ShardedTracker:
     """Drives one TrackBatch, or several (groups of problems that are software-pipelined against each other's
-    collectives), in sharded mode. Collective path: RcclDirect (in-stream, default when every rank can set it up),
+    collectives), in sharded mode. Collective path: RcclDirect (in-stream, when asked for and every rank can set it up),
     else torch.distributed (asynchronous on the process group's stream; ``wait()`` makes the compute stream wait,
-    not the host), else -- ``staged`` -- through host memory with any backend (tests)."""
+    not the host), else -- ``staged`` -- through host memory with any backend (tests). Default: torch.distributed;
+    RcclDirect is opt-in (``direct=True`` or ICTR_RCCL_DIRECT=1)."""
 
-    def __init__(self, batch, group=None, staged=False, direct=True):
+    def __init__(self, batch, group=None, staged=False, direct=None, p2p=False):
+        import os
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -174,8 +337,9 @@ class ShardedTracker:
         self.batch = self.batches[0]
         self.group, self.staged = group, staged
         self.reds, self._hosts = [], []
-        import os
-        want_direct = (direct and not staged and dist.get_backend(group) == "nccl"
+        if direct is None:  # opt-in: the in-stream RCCL path has never run with more than one rank
+            direct = os.environ.get("ICTR_RCCL_DIRECT") == "1"
+        want_direct = (bool(direct) and not staged and dist.get_backend(group) == "nccl"
                        and not os.environ.get("ICTR_NO_RCCL_DIRECT"))
         # direct path with several groups: every group gets its own stream AND its own communicator, so that one
         # group's in-stream all-reduce (pure link latency) runs while the other group's kernels use the GPU
@@ -193,26 +357,57 @@ class ShardedTracker:
             self._hosts.append(torch.zeros(b.B * RED_STRIDE, dtype=torch.float32) if staged else None)
         self.red = self.reds[0]
         torch.cuda.synchronize()  # the zero-fills above ran on the current stream
-        self.direct = None
-        if want_direct:
-            try:
-                self.direct = [RcclDirect(torch, dist, group) for _ in self.batches]
-            except Exception as exc:  # keep working through torch.distributed
+        self.direct, self.p2p = None, None
+        if p2p and not staged:
+            boxes = [P2PDirect(torch, dist, group, b.B * RED_STRIDE) for b in self.batches]
+            if all(c.ok for c in boxes):
+                self.p2p = boxes
+            else:
                 import sys
-                print(f"[ictr.dist] direct RCCL unavailable ({exc!r}); using torch.distributed", file=sys.stderr)
-                self.direct = None
-            # every rank must take the same path: agree on it through the torch group
-            flag = torch.tensor([1.0 if self.direct is not None else 0.0], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            if float(flag.item()) < 1.0:
-                self.direct = None
-            if self.direct is None:
+                print("[ictr.dist] P2P exchange unavailable (" + "; ".join(c.why for c in boxes if c.why) +
+                      "); using torch.distributed", file=sys.stderr)
+                for c in boxes:
+                    c.close()
+        if want_direct and self.p2p is None:
+            # every rank builds the same number of communicators in the same order; each construction is itself a
+            # lock-step sequence of collectives that ends with the same verdict on every rank (RcclDirect)
+            comms = [RcclDirect(torch, dist, group) for _ in self.batches]
+            if all(c.ok for c in comms):
+                self.direct = comms
+            else:
+                import sys
+                print("[ictr.dist] direct RCCL unavailable (" + "; ".join(c.why for c in comms if c.why) +
+                      "); using torch.distributed", file=sys.stderr)
+                for c in comms:
+                    c.close()
                 for b in self.batches:
                     b.set_stream(torch.cuda.current_stream().cuda_stream)
                 self._streams = [torch.cuda.current_stream().cuda_stream for _ in self.batches]
 
+    def close(self):
+        """Destroy the direct communicators (if any); the tracker falls back to torch.distributed afterwards."""
+        if self.direct is not None:
+            self._torch.cuda.synchronize()
+            for c in self.direct:
+                c.close()
+            self.direct = None
+        if self.p2p is not None:
+            self._torch.cuda.synchronize()
+            for c in self.p2p:
+                c.close()
+            self.p2p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _allreduce_async(self, g):
         dist = self._dist
+        if self.p2p is not None:  # in-stream, one hop
+            self.p2p[g].all_reduce_sum_f32(self.reds[g].data_ptr(), self.reds[g].numel(), self._streams[g])
+            return _Done()
         if self.direct is not None:  # in-stream: nothing to wait for afterwards
             self.direct[g].all_reduce_sum_f32(self.reds[g].data_ptr(), self.reds[g].numel(), self._streams[g])
             return _Done()
@@ -235,4 +430,7 @@ class ShardedTracker:
                              for g, b in enumerate(self.batches)])
 
     def poses(self):
-        return np.concatenate([b.poses() for b in self.batches], 0)
+        out = np.concatenate([b.poses() for b in self.batches], 0)
+        if self.p2p is not None and any(c.error() for c in self.p2p):
+            raise RuntimeError("P2P exchange timed out: a peer did not deliver its records (results are invalid)")
+        return out

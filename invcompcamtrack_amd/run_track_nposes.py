@@ -1,6 +1,6 @@
 """Many-poses driver, file-compatible with the reference's run_track_nposes (run_track_nposes.cpp:133-454):
 
-  python -m invcompcamtrack_amd.run_track_nposes input.txt output.txt
+  python -m invcompcamtrack_amd.run_track_nposes input.txt output.txt [--gpus N]
 
 For every RANSAC pose sample: gather its inlier 3-D points, track the pose forward over nFwd frame pairs and
 backward over nBack frame pairs (SetPose/TrackPose chains, run_track_nposes.cpp:232-258), reproject with the final
@@ -14,6 +14,9 @@ calls (patches of points that leave the view) -- is the reference's. One referen
 kept: run_track_nposes.cpp:281 sets op.dopatchnorm = true for the NCC patches of the FIRST sample and never resets
 it, so every later sample is tracked with patch normalisation on. Hence sample 0 runs alone first when the input
 asks for dopatchnorm = 0.
+
+--gpus N: the samples are split into N contiguous ranges, one process per GPU tracks and scores its range, rank 0
+gathers the results (a host-side gather of a few KB: no GPU collective on this axis) and writes the file.
 """
 from __future__ import annotations
 
@@ -100,9 +103,20 @@ def _ncc(cam, op_ncc, pyrs, inp, pts2d, nsamples):
     return out
 
 
-def run(inp, images=None):
-    """inp: dict from io_formats.read_nposes_input. images: optional list of grey float32 arrays (else the files are
-    read). Returns (out_corr, out_pose) as the reference writes them."""
+def partition_samples(nsamples, world):
+    """Contiguous, balanced ranges of pose samples: rank r owns [lo, hi). The samples are mutually independent
+    (run_track_nposes.cpp:193), so this axis needs no collective in the data path."""
+    base, rem = divmod(nsamples, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _run_local(inp, images, sample_ids):
+    """Track and score the given samples on this process's GPU. Returns {sid: (corr, poses)}."""
     o = inp["op"]
     op = optparam(o["lv_f"], o["lv_l"], o["psz"], o["maxiter"], o["normdp_ratio"], o["donorm"], o["dopatchnorm"],
                   o["maxpttrack"], o["verbosity"])
@@ -114,26 +128,99 @@ def run(inp, images=None):
     S = len(inp["poses"])
     out_pose = [np.zeros((noimages, 6)) for _ in range(S)]
     pts2d = [None] * S
-    if S > 0:
-        first = [0] if not op.dopatchnorm else list(range(S))
-        _track_samples(cam, op, pyrs, first, inp, out_pose, pts2d)
-        rest = [s for s in range(S) if s not in first]
-        op.dopatchnorm = True  # run_track_nposes.cpp:281 -- stays on for every later sample
+    ids = list(sample_ids)
+    if ids:
+        # run_track_nposes.cpp:281: dopatchnorm is switched on while sample 0 is scored and never reset, so sample 0
+        # is tracked with the input's setting and EVERY later sample with patch normalisation on -- a property of
+        # the sample's index, not of the rank that owns it
+        first = [sid for sid in ids if sid == 0] if not op.dopatchnorm else ids
+        if first:
+            _track_samples(cam, op, pyrs, first, inp, out_pose, pts2d)
+        rest = [sid for sid in ids if sid not in first]
+        op.dopatchnorm = True
         for lo in range(0, len(rest), 4096):
             _track_samples(cam, op, pyrs, rest[lo:lo + 4096], inp, out_pose, pts2d)
     op.dopatchnorm = True
-    out_corr = _ncc(cam, op, pyrs, inp, pts2d, S)
-    return out_corr, out_pose
+    corr = _ncc(cam, op, pyrs, inp, [pts2d[sid] for sid in ids], len(ids))
+    return {sid: (corr[k], out_pose[sid]) for k, sid in enumerate(ids)}
+
+
+def merge_results(parts, nsamples):
+    """parts: per-rank dicts {sid: (corr, poses)} -> (out_corr, out_pose) in sample order, as the reference writes."""
+    merged = {}
+    for part in parts:
+        for sid, v in part.items():
+            if sid in merged:
+                raise ValueError(f"sample {sid} was tracked by two ranks")
+            merged[sid] = v
+    missing = [sid for sid in range(nsamples) if sid not in merged]
+    if missing:
+        raise ValueError(f"samples {missing[:8]} were tracked by no rank")
+    return [merged[sid][0] for sid in range(nsamples)], [merged[sid][1] for sid in range(nsamples)]
+
+
+def run(inp, images=None, dist=None):
+    """inp: dict from io_formats.read_nposes_input. images: optional list of grey float32 arrays (else the files are
+    read). Returns (out_corr, out_pose) as the reference writes them.
+    dist: an initialised torch.distributed module -> the pose samples are split over the ranks in contiguous ranges
+    (one process per GPU, no collective in the data path); rank 0 gathers and returns the merged result, the other
+    ranks return (None, None)."""
+    S = len(inp["poses"])
+    if dist is None:
+        return merge_results([_run_local(inp, images, range(S))], S)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = partition_samples(S, world)[rank]
+    mine = _run_local(inp, images, range(lo, hi))
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0)
+    if rank != 0:
+        return None, None
+    return merge_results(parts, S)
+
+
+def _launch_ranks(ngpus, argv):
+    """`--gpus N` from a plain shell: start N ranks (one per GPU) with torch.distributed.run before this process
+    touches the GPU; rank 0 writes the output file."""
+    import os
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "invcompcamtrack_amd.run_track_nposes"] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main(argv=None):
+    import os
     a = sys.argv[1:] if argv is None else list(argv)
+    ngpus = 1
+    if "--gpus" in a:
+        i = a.index("--gpus")
+        ngpus = int(a[i + 1])
+        a = a[:i] + a[i + 2:]
     if len(a) != 2:
         print(__doc__)
         return 2
+    if ngpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _launch_ranks(ngpus, a + ["--gpus", str(ngpus)])
+    dist = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        from . import _lib
+        # the host-side gather is tiny (poses + correlations): gloo; the GPUs never talk to each other on this axis
+        dist.init_process_group("gloo")
+        _lib.check(_lib.load().ictr_set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, _lib.load().ictr_device_count())))
     inp = iof.read_nposes_input(a[0])
-    out_corr, out_pose = run(inp)
-    iof.write_nposes_result(a[1], out_corr, out_pose)
+    out_corr, out_pose = run(inp, dist=dist)
+    if out_corr is not None:
+        iof.write_nposes_result(a[1], out_corr, out_pose)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

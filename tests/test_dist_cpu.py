@@ -223,3 +223,62 @@ def test_global_norm_matches_single_rank_formula():
              torch.tensor([float(((b - mean[:, None]) ** 2).sum())], dtype=torch.float64)]
     m, v = global_norm(a, dist=FakeDist(other))
     assert np.allclose(m, mean) and np.isclose(v, ((allp - mean[:, None]) ** 2).sum(0).mean())
+
+
+def _worker_norm(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from invcompcamtrack_amd.dist import global_norm, shard_slices, sharded_set3dpoints
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    allp = rng.normal(size=(3, 37)) * np.array([[3.0], [1.0], [0.5]]) + np.array([[4.0], [-2.0], [9.0]])
+    lo, hi = shard_slices(37, world)[rank]
+    mine = np.ascontiguousarray(allp[:, lo:hi])
+    mean, var = global_norm(mine)                      # through the real process group (CPU tensors for gloo)
+
+    class Op:
+        donorm = True
+
+    class FakeBatch:                                   # records what the engine would be handed
+        op = Op()
+
+        def Set3Dpoints_norm(self, problem, pts, ms, vv):
+            self.call = (problem, pts.copy(), np.array(ms), vv)
+            pts -= np.asarray(ms)[:, None]             # the engine normalises in place (odometer.cpp:207-212)
+            pts /= vv
+
+        def Set3Dpoints(self, problem, pts):
+            self.call = ("plain", problem)
+
+    fb = FakeBatch()
+    m2, v2 = sharded_set3dpoints(fb, 3, mine)
+    q.put((rank, mean, var, m2, v2, fb.call[0], mine.copy(), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_norm_and_sharded_set3dpoints_two_ranks_gloo():
+    """donorm with sharded points: mean / mean squared radius must be those of the UNION of the shards
+    (odometer.cpp:193-214), obtained through torch.distributed itself (CPU tensors under gloo, GPU tensors
+    under nccl), and handed to the engine by dist.sharded_set3dpoints."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_norm, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    allp = rng.normal(size=(3, 37)) * np.array([[3.0], [1.0], [0.5]]) + np.array([[4.0], [-2.0], [9.0]])
+    mean = allp.mean(1)
+    var = ((allp - mean[:, None]) ** 2).sum(0).mean()
+    for rank, m, v, m2, v2, prob, pts_after, (lo, hi) in res:
+        assert np.allclose(m, mean, rtol=1e-14) and np.isclose(v, var, rtol=1e-14)
+        assert np.array_equal(m, m2) and v == v2 and prob == 3
+        assert np.allclose(pts_after, (allp[:, lo:hi] - mean[:, None]) / var)   # normalised in place, global statistics
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]     # identical on both ranks

@@ -3,6 +3,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from invcompcamtrack_amd import io_formats as iof
 
@@ -92,3 +93,56 @@ def test_cxx_facade_compiles_against_the_c_abi(tmp_path):
                         "-Wl,-rpath," + os.path.join(ROOT, "invcompcamtrack_amd")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert subprocess.run([str(tmp_path / "abi")]).returncode == 0
+
+
+def _worker_nposes(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from invcompcamtrack_amd import run_track_nposes as drv
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    seen = []
+
+    def fake_local(inp, images, sample_ids):     # stands in for the GPU work: results that identify sample and rank
+        ids = list(sample_ids)
+        seen.extend(ids)
+        return {sid: (np.full(3, sid + 0.5), np.full((2, 6), 10.0 * sid + rank)) for sid in ids}
+
+    drv._run_local = fake_local
+    inp = {"poses": [np.zeros(6)] * 7}
+    corr, pose = drv.run(inp, dist=dist)
+    q.put((rank, seen, corr, pose))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_track_nposes_sample_sharding_two_ranks_gloo():
+    """`run_track_nposes --gpus N`: contiguous sample ranges per rank, no collective in the data path, rank 0 gathers
+    and merges in sample order (run_track_nposes.cpp:193: the samples are independent)."""
+    import socket
+    import torch.multiprocessing as mp
+    from invcompcamtrack_amd import run_track_nposes as drv
+    assert drv.partition_samples(7, 2) == [(0, 4), (4, 7)] and drv.partition_samples(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    with pytest.raises(ValueError):
+        drv.merge_results([{0: (1, 2)}, {0: (1, 2)}], 1)
+    with pytest.raises(ValueError):
+        drv.merge_results([{0: (1, 2)}], 2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_nposes, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2, 3] and res[1][1] == [4, 5, 6]
+    assert res[1][2] is None and res[1][3] is None                      # only rank 0 holds the merged result
+    corr, pose = res[0][2], res[0][3]
+    assert [c[0] for c in corr] == [sid + 0.5 for sid in range(7)]      # sample order
+    assert [p_[0, 0] for p_ in pose] == [0, 10, 20, 30, 41, 51, 61]     # samples 4-6 came from rank 1

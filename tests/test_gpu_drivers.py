@@ -145,6 +145,10 @@ def test_run_track_nposes_matches_serial_oracle(oracle, tmp_path, dopatchnorm):
         assert corr_g[sid].shape == (len(inl[sid]),)
         assert np.abs(corr_g[sid] - corr_o[sid]).max() <= 2e-3  # printed with 3 significant digits
         assert corr_g[sid].min() >= 0.0 and np.median(corr_g[sid]) > 0.9
+    # --gpus 2: the samples split over two ranks (here both on the one GPU of the box), merged by rank 0: same file
+    fout2 = str(tmp_path / "outfileRANSAC_2ranks.txt")
+    assert drv_np.main([fin, fout2, "--gpus", "2"]) == 0
+    assert open(fout2).read() == open(fout).read()
 
 
 @pytest.mark.parametrize("psz", [8, 4, 12])
