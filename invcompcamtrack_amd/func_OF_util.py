@@ -110,16 +110,17 @@ def func_extract_bil_patch(ptin, img, pz, do_zeromean=0, use_mask=None, do_log=0
     (utilities.cpp:72-77): samples at x - pz//2 ... x + pz//2 - 1. Returns (pz*pz, C) when do_flatten else
     (pz, pz, C)."""
     ptin = np.asarray(ptin, dtype=float)
-    ptfloor = np.floor(ptin).astype(int)
-    ptceil = ptfloor + 1
-    ptf = ptin - ptfloor
-    w = np.array([ptf[0] * ptf[1], (1 - ptf[0]) * ptf[1], ptf[0] * (1 - ptf[1]), (1 - ptf[0]) * (1 - ptf[1])])
-    pz2 = pz // 2
-    pa = img[(ptceil[1] - pz2):(ptceil[1] + pz2), (ptceil[0] - pz2):(ptceil[0] + pz2), :]
-    pb = img[(ptceil[1] - pz2):(ptceil[1] + pz2), (ptfloor[0] - pz2):(ptfloor[0] + pz2), :]
-    pc = img[(ptfloor[1] - pz2):(ptfloor[1] + pz2), (ptceil[0] - pz2):(ptceil[0] + pz2), :]
-    pd = img[(ptfloor[1] - pz2):(ptfloor[1] + pz2), (ptfloor[0] - pz2):(ptfloor[0] + pz2), :]
-    pf = pa * w[0] + pb * w[1] + pc * w[2] + pd * w[3]
+    cell = np.floor(ptin).astype(int)          # integer pixel below-left of the point
+    fx, fy = ptin - cell                       # sub-pixel fractions: the four windows' weights are patch-constant
+    half = pz // 2                             # Python-2 integer `/`: an odd pz gives a (pz-1) x (pz-1) patch
+    x0, y0 = cell[0] - half, cell[1] - half
+
+    def window(dy, dx):                        # the 2*half square whose first sample is (x0 + dx, y0 + dy)
+        return img[(y0 + dy):(y0 + dy + 2 * half), (x0 + dx):(x0 + dx + 2 * half), :]
+
+    # taps in the tracker's order (utilities.cpp:107): (x+1,y+1), (x,y+1), (x+1,y), (x,y) of the integer cell
+    pf = (window(1, 1) * (fx * fy) + window(1, 0) * ((1 - fx) * fy)
+          + window(0, 1) * (fx * (1 - fy)) + window(0, 0) * ((1 - fx) * (1 - fy)))
     return _postprocess(pf, do_zeromean, use_mask, do_log, do_unitnorm, do_flatten)
 
 
@@ -143,14 +144,12 @@ def func_get_pat_cosmask(psize):
 
 
 def gauss2Dfilter(shape=(3, 3), sigma=0.5):
-    """Normalised 2-D Gaussian (MATLAB fspecial('gaussian') clone, with its centre at ceil((n-1)/2))."""
-    m, n = [np.ceil((ss - 1.) / 2.) for ss in shape]
-    y, x = np.ogrid[0:shape[0], 0:shape[1]]
-    y = y.astype(float) - float(m)
-    x = x.astype(float) - float(n)
-    h = np.exp(-(x * x + y * y) / (2. * sigma * sigma))
-    h[h < np.finfo(h.dtype).eps * h.max()] = 0
-    sumh = h.sum()
-    if sumh != 0:
-        h /= sumh
-    return h
+    """Normalised 2-D Gaussian window with MATLAB fspecial('gaussian') conventions: centre at ceil((n-1)/2) per
+    axis, taps below machine epsilon relative to the peak dropped, unit sum."""
+    rows, cols = int(shape[0]), int(shape[1])
+    dy = np.arange(rows, dtype=float)[:, None] - float(np.ceil((rows - 1.0) / 2.0))
+    dx = np.arange(cols, dtype=float)[None, :] - float(np.ceil((cols - 1.0) / 2.0))
+    kernel = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma))
+    kernel[kernel < np.finfo(kernel.dtype).eps * kernel.max()] = 0.0
+    total = kernel.sum()
+    return kernel / total if total != 0 else kernel

@@ -75,3 +75,48 @@ def test_forward_backward_consistency_and_oftrack_loop(tmp_path):
     assert 0.1 < np.nanmedian(mv) < 10
     import os
     assert os.path.getsize(str(tmp_path / "tracks.npz")) > 1000
+
+
+def test_config4_full_size_properties():
+    """BASELINE config 4 at its stated size: 4096 independent 31x31 patches on a 1920x1080 pair, 3 levels (the
+    run_OF_point_track-style workload). The NumPy oracle takes minutes at this size, so the full-size run is held to
+    size-independent properties: (1) identical frames -> zero flow, one iteration per level; (2) a frame pair that
+    differs by a pure integer shift -> every interior patch recovers the shift; (3) forward then backward tracking
+    returns to the start; (4) same input, same bits; (5) a 64-patch subset of the same launch geometry agrees with
+    the NumPy oracle. Build-defined algorithm: parity unpinned by the reference."""
+    from oracle import np_patchflow as NP
+    from oracle import oracle as O
+    w, h, lv_f, psz, K = 1920, 1080, 2, 31, 4096
+    sc = synth.make_scene(w, h, n_points=10, seed=3, dp_gt=np.array([0.02, -0.015, 0.03, 0.003, -0.002, 0.004]))
+    pa, pb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
+    rng = np.random.default_rng(7)
+    gx, gy = np.meshgrid(np.linspace(60, w - 60, 64), np.linspace(60, h - 60, 64))
+    pts = (np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-1.5, 1.5, (K, 2))).astype(np.float32)
+    # (1) identity
+    new, ok, it = pf.track_points(pa, pa, pts, psz=psz, lv_f=lv_f, maxiter=10, eps=0.01)
+    assert ok.all() and np.array_equal(new, pts) and np.all(it == lv_f + 1)
+    # (2) pure integer shift (exact re-sampling: frame B(x) = A(x - s))
+    s = np.array([5, -3])
+    shifted = np.roll(sc["img_a"], (int(s[1]), int(s[0])), axis=(0, 1)).astype(np.float32)
+    ps = ic.Pyramid(shifted, lv_f, psz)
+    new, ok, it = pf.track_points(pa, ps, pts, psz=psz, lv_f=lv_f, maxiter=10, eps=0.002)
+    inner = (pts[:, 0] > 80) & (pts[:, 0] < w - 80) & (pts[:, 1] > 80) & (pts[:, 1] < h - 80)
+    assert ok[inner].mean() > 0.995
+    err = np.abs(new[inner & ok] - pts[inner & ok] - s[None, :])
+    assert np.median(err) < 0.02 and np.percentile(err, 99) < 0.2
+    # (3) forward-backward on the real pair, (4) determinism
+    fwd, okf, _ = pf.track_points(pa, pb, pts, psz=psz, lv_f=lv_f, maxiter=10, eps=0.005)
+    fwd2, okf2, _ = pf.track_points(pa, pb, pts, psz=psz, lv_f=lv_f, maxiter=10, eps=0.005)
+    assert np.array_equal(okf, okf2) and np.array_equal(fwd[okf], fwd2[okf])
+    assert okf.mean() > 0.97
+    back, okb, _ = pf.track_points(pb, pa, fwd[okf], psz=psz, lv_f=lv_f, maxiter=10, eps=0.005)
+    fb = np.linalg.norm(back[okb] - pts[okf][okb], axis=1)
+    assert okb.mean() > 0.97 and np.median(fb) < 0.02 and np.percentile(fb, 95) < 0.25
+    d = np.linalg.norm(fwd[okf] - pts[okf], axis=1)
+    assert 1.0 < np.median(d) < 60          # the plane really moved
+    # (5) a subset against the NumPy oracle (same frames, same parameters)
+    sub = np.arange(0, K, 64)
+    oa, ob = O.Pyramid(sc["img_a"], lv_f, psz), O.Pyramid(sc["img_b"], lv_f, psz)
+    new_o, ok_o, it_o = NP.track_points(oa, ob, pts[sub], psz, lv_f, maxiter=10, eps=0.005)
+    both = okf[sub] & ok_o
+    assert both.sum() >= 60 and np.abs(fwd[sub][both] - new_o[both]).max() <= 1e-2

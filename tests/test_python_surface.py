@@ -159,3 +159,113 @@ def test_extract_nn_patch_and_masks():
     assert np.isclose(g.sum(), 1.0) and g[2, 2] == g.max() and np.allclose(g, g.T)
     g3 = fu.gauss2Dfilter()
     assert g3.shape == (3, 3) and np.isclose(g3[1, 1] / g3[0, 1], np.exp(1 / (2 * 0.25)))
+
+
+def test_extract_patch_python2_semantics_and_options():
+    """func_OF_util.py:87-165 restated for Python 3. Pinned by properties of the reference's text (the module is
+    Python-2 only and ships no expected values: parity unpinned by reference outputs):
+    integer `/` (odd pz -> (pz-1)^2 samples), integer points reproduce the image, linearity in the image, the option
+    order log -> zero-mean -> mask -> unit-norm, the 1e-15 norm floor, flatten = column per channel, NN = plain slice."""
+    import itertools
+    rng = np.random.default_rng(0)
+    img = rng.uniform(1, 200, (40, 48, 3))
+    for pz in (4, 5, 8, 9):   # odd sizes: Python-2 `pz/2` floors, the patch is (pz-1) x (pz-1)
+        side = 2 * (pz // 2)
+        a = fu.func_extract_bil_patch(np.array([20.25, 15.5]), img, pz, do_flatten=0)
+        assert a.shape == (side, side, 3)
+        f = fu.func_extract_bil_patch(np.array([20.25, 15.5]), img, pz)
+        assert f.shape == (side * side, 3) and np.array_equal(f[:, 1], a[:, :, 1].ravel())
+        # integer point: weights (0,0,0,1) -> exactly the window starting pz//2 below-left of the point
+        b = fu.func_extract_bil_patch(np.array([20.0, 15.0]), img, pz, do_flatten=0)
+        assert np.array_equal(b, img[15 - pz // 2:15 + pz // 2, 20 - pz // 2:20 + pz // 2, :])
+        n = fu.func_extract_NN_patch([20, 15], img, pz, do_flatten=0)
+        assert np.array_equal(n, b)
+    # bilinear: exact on an affine image, at any sub-pixel point
+    yy, xx = np.mgrid[0:40, 0:48].astype(float)
+    ramp = (3.0 * xx - 2.0 * yy + 7.0)[:, :, None]
+    for pt in ([20.3, 12.7], [10.999, 30.001], [25.5, 25.5]):
+        a = fu.func_extract_bil_patch(np.array(pt), ramp, 6, do_flatten=0)[:, :, 0]
+        ys, xs = np.mgrid[0:6, 0:6].astype(float)
+        want = 3.0 * (pt[0] - 3 + xs) - 2.0 * (pt[1] - 3 + ys) + 7.0
+        assert np.allclose(a, want, atol=1e-10)
+    # linearity in the image
+    i2 = rng.uniform(1, 200, (40, 48, 3))
+    pa, pb = (fu.func_extract_bil_patch(np.array([17.2, 9.9]), im, 8) for im in (img, i2))
+    pab = fu.func_extract_bil_patch(np.array([17.2, 9.9]), 2.0 * img - 0.5 * i2, 8)
+    assert np.allclose(pab, 2.0 * pa - 0.5 * pb, atol=1e-9)
+    # option order: log first (clamped to [0.1, 255]), then zero-mean, mask, unit norm
+    m = fu.func_get_pat_cosmask(8)
+    big = np.full((40, 48, 1), 1000.0)
+    big[10:14] = 0.0
+    for zm, um, lg, un in itertools.product((0, 1), (None, m), (0, 1), (0, 1)):
+        got = fu.func_extract_bil_patch(np.array([20.4, 12.6]), big, 8, do_zeromean=zm, use_mask=um, do_log=lg,
+                                        do_unitnorm=un, do_flatten=0)[:, :, 0]
+        want = fu.func_extract_bil_patch(np.array([20.4, 12.6]), big, 8, do_flatten=0)[:, :, 0].copy()
+        if lg:
+            want = np.log(np.minimum(255, np.maximum(0.1, want)))
+        if zm:
+            want = want - want.mean()
+        if um is not None:
+            want = want * um
+        if un:
+            want = want / max(np.linalg.norm(want), 1e-15)
+        assert np.allclose(got, want, atol=1e-12), (zm, um is not None, lg, un)
+    # the norm floor: an all-zero patch stays finite (0 / 1e-15)
+    z = fu.func_extract_bil_patch(np.array([20.4, 12.6]), np.zeros((40, 48, 2)), 8, do_unitnorm=1)
+    assert np.all(z == 0) and np.all(np.isfinite(z))
+    # NN patch at the image border: numpy slicing clips, like the reference's plain slice
+    edge = fu.func_extract_NN_patch([46, 38], img, 8, do_flatten=0)
+    assert edge.shape == (6, 6, 3) and np.array_equal(edge, img[34:42, 42:50, :])
+    # the NN patch without options is a VIEW of the image (the reference slices and returns)
+    v = fu.func_extract_NN_patch([20, 15], img, 4, do_flatten=0)
+    assert np.shares_memory(v, img)
+
+
+def test_cosmask_and_gauss_windows_properties():
+    """func_OF_util.py:169-187: radial cosine window (1 at the centre ring, 0 from radius psize/2 on, 8-fold
+    symmetric) and fspecial-style Gaussian (unit sum, symmetric, centre at ceil((n-1)/2), separable ratios)."""
+    for ps in (4, 7, 8, 15):
+        m = fu.func_get_pat_cosmask(ps)
+        assert m.shape == (ps, ps) and np.allclose(m, m.T) and m.min() >= -1e-16 and m.max() <= 1.0
+        c = ps // 2
+        want = np.cos(min(1.0, np.sqrt((0.5 ** 2 + 0.5 ** 2) / float(c ** 2))) * np.pi / 2)
+        assert np.isclose(m[c, c], want)                       # the sample next to the centre
+        assert np.isclose(m[0, 0], 0.0, atol=1e-12) or ps % 2   # corners lie beyond radius psize/2
+        if ps % 2 == 0:
+            assert np.allclose(m, m[::-1, ::-1])
+    for shape, sig in (((3, 3), 0.5), ((5, 5), 1.0), ((5, 9), 2.0), ((4, 6), 1.5), ((31, 31), 0.2)):
+        g = fu.gauss2Dfilter(shape, sig)
+        assert g.shape == shape and np.isclose(g.sum(), 1.0) and g.min() >= 0
+        cy, cx = int(np.ceil((shape[0] - 1) / 2.0)), int(np.ceil((shape[1] - 1) / 2.0))
+        assert g[cy, cx] == g.max()
+        if shape[0] > cy + 1 and cx + 1 < shape[1] and g[cy, cx + 1] > 0:
+            assert np.isclose(g[cy, cx + 1] / g[cy, cx], np.exp(-1.0 / (2 * sig * sig)))
+            assert np.isclose(g[cy + 1, cx + 1] / g[cy, cx], np.exp(-2.0 / (2 * sig * sig)))
+    g = fu.gauss2Dfilter((31, 31), 0.2)
+    assert np.count_nonzero(g) < 31 * 31   # taps below eps * peak are dropped, as fspecial does
+    assert np.allclose(fu.gauss2Dfilter((3, 3), 0.5), fu.gauss2Dfilter())
+
+
+def test_check_pmc_rejects_over_budget_lines(tmp_path):
+    """tools/check_pmc.py: the static guard against the rocprofv3 abort of round 1 (a `pmc:` line over the gfx950
+    per-block slot budget: signal 6, then a 7-minute silent hang)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "check_pmc.py")
+    good = tmp_path / "good.txt"
+    good.write_text("pmc: FETCH_SIZE TCC_HIT_sum\npmc: WRITE_SIZE TCC_MISS_sum TCC_REQ_sum\n"
+                    "pmc: SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                    "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM\n")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("pmc: TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum FETCH_SIZE\n")   # the line that aborted the profiler
+    nine = tmp_path / "nine.txt"
+    nine.write_text("pmc: " + " ".join(f"SQ_C{k}" for k in range(9)) + "\n")
+    assert subprocess.run([_sys.executable, tool, str(good)]).returncode == 0
+    r = subprocess.run([_sys.executable, tool, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "TCC: 6 slots needed, 4 available" in r.stdout
+    assert subprocess.run([_sys.executable, tool, str(nine)], capture_output=True).returncode == 1
+    # every counter file committed under profiles/ passes
+    import glob
+    files = sorted(glob.glob(os.path.join(root, "profiles", "pmc_*.txt")))
+    assert files and subprocess.run([_sys.executable, tool] + files, capture_output=True).returncode == 0
