@@ -11,13 +11,18 @@ projection + 3 levels x [setup + 10 GN iterations]) of a batch of B independent 
 pair has its own pyramids and patch buffers, so one GN iteration streams B x 33 MB = 1.06 GB, far beyond the 256 MB
 Infinity Cache; measured: 16 pairs 238, 32 pairs 266, 64 pairs 270 Gpix/s -- fixed launch/tail costs amortise).
 Inputs (pyramids, 3-D points) are resident in HBM before the timed region; every step ends with its poses on the
-host. In single-GPU mode two engines take the steps in turn on one stream so that the host prepares step i+1 while
-the GPU runs step i (kernels never overlap; --no-pipeline restores strict alternation).
+host. Single-GPU mode: the B pairs of a step are held by S = 2 engines of B/2 pairs on two HIP streams (--streams),
+which run concurrently -- one engine's latency-bound setup kernel, tails and launch gaps overlap the other's HBM-bound
+iteration kernel -- and two such step holders alternate, so that the host prepares step i+1 while the GPU runs step i
+(--no-pipeline: one holder; --streams 1: strictly serial kernels, the round-1 default).
 
   value        = aligned pixels / s  (pixels entering the residual, all levels, all problems, all ranks) in Mpix/s
   roofline     = the GN-iteration kernel k_iter8: algorithmic bytes (16 B per patch pixel: T, Gx, Gy, one
-                 current-frame texel) per launch / mean duration of all its launches, measured
-                 with HIP events on the kernel's stream over the timed steps, vs 8 TB/s HBM3E.
+                 current-frame texel) per launch / duration of a launch, measured with HIP events on
+                 the kernel's stream around every launch of the timed steps, vs 8 TB/s HBM3E. With concurrent
+                 engines a launch's wall-clock duration includes the time it shared the GPU with the other stream's
+                 launches, so the duration used is the FAIR SHARE (union busy time of all k_iter8 intervals / number
+                 of launches; roofline.duration_basis); the wall duration rocprofv3 --stats shows is reported beside it.
   cpu_baseline = the oracle (C restatement of the reference, one thread, -O3 -msse4 -mavx) timed on the same
                  workload for one frame pair (a bounded sample), on this host's cores.
 
@@ -56,10 +61,11 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel-selection bits for A/B runs (include/ictr.h, ictr_odometer_set_variant)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="single-GPU mode: split the B pairs over this many engines on their own HIP streams and run "
-                         "them concurrently (2: +8 %% throughput, but launches overlap, so per-launch durations -- "
-                         "and the roofline derived from them -- are no longer solo durations)")
+                         "them concurrently (default 2: one engine's latency-bound setup kernel, tails and launch gaps "
+                         "overlap the other's HBM-bound iteration kernel; the roofline then uses fair-share launch "
+                         "durations, see roofline.duration_basis). 1 = strictly serial kernels")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one engine, host and GPU strictly alternate (the pre-pipelining behaviour)")
     ap.add_argument("--groups", type=int, default=0,
@@ -271,38 +277,45 @@ def main():
     op, pyrs, scenes = inp["op"], inp["pyrs"], inp["scenes"]
     B, P, n_pts = args.batch, args.psz, inp["n_pts"]
     sharded = world > 1 or args.force_sharded
-    tracker = None
+    tracker = None      # sharded mode: the ShardedTracker chosen below
+    holders = None      # single-GPU mode: D step holders (D = 2: the host prepares step i+1 while the GPU runs step i)
+    n_streams = 1
+
+    class StepGroup:
+        """The engines that together hold one step (B frame pairs): one engine of B / S pairs per HIP stream. With
+        S = 2 the two engines run concurrently: one's latency-bound setup kernel, tails and launch gaps overlap the
+        other's HBM-bound iteration kernel."""
+
+        def __init__(self, engs):
+            self.engs, self.per = engs, B // len(engs)
+
+        def setpose_all(self):
+            for b in range(B):
+                pa, pb = pyrs[b]
+                self.engs[b // self.per].SetPose(b % self.per, scenes[b % 2]["p_a"], pa, pb)
+
+        def track(self):
+            for e in self.engs:
+                e.track_async()
+
+        def poses(self):
+            return np.concatenate([e.poses() for e in self.engs], 0)
+
     if sharded:
         from invcompcamtrack_amd.dist import ShardedTracker
-        engines = None  # chosen below (group-count autotuning)
     else:
-        # Two engines take the steps in turn on one stream: while the GPU runs step i on one, the host prepares and
-        # enqueues step i+1 on the other, then collects step i's poses (each engine waits for its own end-of-tracking
-        # event only). Kernels never overlap; the GPU just does not idle during the host's SetPose / enqueue work.
-        if args.streams > 1:
-            if B % args.streams:
-                raise SystemExit("--streams must divide --batch")
-
-            class ConcurrentEngines:  # same interface as ShardedTracker: track() enqueues everything, poses() collects
-                direct = None
-
-                def __init__(self, engs):
-                    self.engs = engs
-                    self.streams = [torch.cuda.Stream() for _ in engs]
-                    for e, st in zip(engs, self.streams):
-                        e.set_stream(st.cuda_stream)
-
-                def track(self):
-                    for e in self.engs:
-                        e.track_async()
-
-                def poses(self):
-                    return np.concatenate([e.poses() for e in self.engs], 0)
-
-            engines = inp["make_engines"](args.streams, split=True)
-            tracker = ConcurrentEngines(engines)
-        else:
-            engines = inp["make_engines"](1 if args.no_pipeline else 2, split=False)
+        n_streams = max(1, args.streams)
+        if B % n_streams:
+            raise SystemExit("--streams must divide --batch")
+        depth = 1 if args.no_pipeline else 2
+        streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [None]
+        holders = []
+        for d in range(depth):
+            engs = inp["make_engines"](n_streams, split=True)
+            for e, st in zip(engs, streams):
+                if st is not None:
+                    e.set_stream(st.cuda_stream)
+            holders.append(StepGroup(engs))
 
     def barrier():
         torch.cuda.synchronize()
@@ -314,42 +327,50 @@ def main():
     ev_iters = np.zeros(args.levels)
     ev_kernel = np.zeros(args.levels)
     ev_first = np.zeros(args.levels)
+    intervals = []      # (start_ms, end_ms) of every accumulate launch of the timed steps, all engines
+    other_intervals = []  # ... and of the setup launches (the other big kernel that shares the GPU with them)
 
     host_t = {"setpose": 0.0, "enqueue": 0.0, "wait_poses": 0.0, "read_events": 0.0}  # host-side phases (stderr)
 
+    def step_engines(h):
+        return h.batches if sharded else h.engs
+
     def enqueue(i):
-        """Hand step i (one batch of B frame pairs) to the GPU; returns the engine that holds it."""
-        eng = tracker if tracker is not None else engines[i % len(engines)]
+        """Hand step i (one batch of B frame pairs) to the GPU; returns the holder of the step."""
+        h = tracker if sharded else holders[i % len(holders)]
         t_a = time.perf_counter()
-        for b in range(B):
-            pa, pb = pyrs[b]
-            if tracker is not None:
-                per = B // len(engines)
-                engines[b // per].SetPose(b % per, scenes[b % 2]["p_a"], pa, pb)
-            else:
-                eng.SetPose(b, scenes[b % 2]["p_a"], pa, pb)
-        t_b = time.perf_counter()
-        if tracker is not None:
-            tracker.track()
+        if sharded:
+            engs = h.batches
+            per = B // len(engs)
+            for b in range(B):
+                pa, pb = pyrs[b]
+                engs[b // per].SetPose(b % per, scenes[b % 2]["p_a"], pa, pb)
         else:
-            eng.track_async()
+            h.setpose_all()
+        t_b = time.perf_counter()
+        h.track()
         host_t["setpose"] += t_b - t_a
         host_t["enqueue"] += time.perf_counter() - t_b
-        return eng
+        return h
 
-    def collect(eng, timed):
-        """Wait for that engine's tracking and fetch its poses (and, in the timed region, its event timings)."""
+    def collect(h, timed):
+        """Wait for that step's tracking and fetch its poses (and, in the timed region, its event timings)."""
         nonlocal ev_setup, ev_iters, ev_kernel, ev_first
         t_a = time.perf_counter()
-        poses = eng.poses()
+        poses = h.poses()
         t_b = time.perf_counter()
         if timed and not args.no_events:
-            for e_ in (engines if tracker is not None else [eng]):
+            for e_ in step_engines(h):
                 a, b_ = e_.level_times()  # zeros in the sharded (phase-driven) mode
                 ev_setup += a
                 ev_iters += b_
                 ev_kernel += e_.kernel_times()
                 ev_first += e_.first_iter_times()
+                st_, en_ = e_.kernel_intervals()
+                intervals.extend((float(x), float(y)) for x, y in zip(st_.ravel(), en_.ravel()) if y > x)
+                if not sharded:
+                    st_, en_ = e_.setup_intervals()
+                    other_intervals.extend((float(x), float(y)) for x, y in zip(st_, en_) if y > x)
         host_t["wait_poses"] += t_b - t_a
         host_t["read_events"] += time.perf_counter() - t_b
         return poses
@@ -357,13 +378,13 @@ def main():
     def run(nsteps, timed):
         poses, pending = None, None
         for i in range(nsteps):
-            eng = enqueue(i)
-            if len(engines) == 1 or tracker is not None:
-                poses = collect(eng, timed)
+            h = enqueue(i)
+            if sharded or len(holders) == 1:
+                poses = collect(h, timed)
             else:
                 if pending is not None:
                     poses = collect(pending, timed)
-                pending = eng
+                pending = h
         if pending is not None:
             poses = collect(pending, timed)
         return poses
@@ -433,6 +454,8 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    if not args.no_events:
+        inp["ic"].timebase_mark()   # launch intervals of the timed steps are measured from here (device idle: barrier above)
     t0 = time.perf_counter()
     poses = run(args.steps, True)
     barrier()
@@ -472,14 +495,14 @@ def main():
                        "frame_pairs_per_step_per_gpu": B, "points_per_pair_per_gpu": n_pts, "psz": P,
                        "levels": args.levels, "maxiter": args.maxiter, "normdp_ratio": 0.0,
                        "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
-                       "host_pipeline": ("2 engines alternate, host one step ahead" if (len(engines) == 2 and tracker is None)
-                                         else "none"),
+                       "host_pipeline": ("2 step holders alternate, host one step ahead"
+                                         if (not sharded and len(holders) == 2) else "none"),
                        "collective": ((("RCCL in-stream (own communicator)" if tracker.direct is not None
                                         else "one-shot P2P mailbox exchange" if getattr(tracker, "p2p", None) is not None
                                         else "torch.distributed (own stream)")
-                                       + f", {len(engines)} group(s) of pairs per rank; tuning ms/step: {tuning}")
+                                       + f", {len(tracker.batches)} group(s) of pairs per rank; tuning ms/step: {tuning}")
                                       if sharded else "n/a"),
-                       "concurrent_streams": (len(engines) if (tracker is not None and not sharded) else 1),
+                       "concurrent_streams": n_streams,
                        "parallelism": "single GPU" if (world == 1 and not sharded) else f"points sharded x{world}, RCCL all-reduce of "
                                                                       "one 27-float record (H 21 + b 6) per pair per iteration"},
             "pose_err_vs_ground_truth": err,
@@ -487,8 +510,10 @@ def main():
         if not args.no_events:
             # the dominant kernel = the GN-iteration accumulate kernel (k_iter8): every launch, at every level, processes
             # the same pairs x N x 64 pixels, so its mean duration over ALL launches is what rocprofv3 --stats reports too
-            pairs_per_launch = engines[0].B            # B, or B/2 per group in the sharded mode
-            n_eng_step = len(engines) if tracker is not None else 1
+            eng_list = tracker.batches if sharded else holders[0].engs
+            pairs_per_launch = eng_list[0].B           # pairs per engine: B / streams (B / groups in the sharded mode)
+            n_eng_step = len(eng_list)
+            overlapping = n_eng_step > 1               # launches of different engines share the GPU
             # The first iteration launch of a level is its own instantiation (k_iter8<..,WH=true>: it also accumulates
             # the 21 H sums that the setup kernel used to produce) and is reported separately; the roofline is that of
             # the regular instantiation, launches 2..maxiter of every level (what rocprofv3 --stats lists as
@@ -515,7 +540,7 @@ def main():
                     continue
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts and tracker is None:
+                    if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts and not overlapping:
                         traffic = tj.get("hbm_bytes_per_launch_mean")
                         traffic_source = (f"profiles/{tname}: rocprofv3 --pmc passes of this command collected in "
                                           "their own runs (FETCH_SIZE x 2 + WRITE_SIZE); static, NOT measured in this run")
@@ -523,30 +548,60 @@ def main():
                 except Exception:
                     traffic = None
             per_level_all = [float(x) / nl * 1e3 for x in ev_kernel]
-            out["roofline"] = {"bound": "hbm", "achieved": alg / t_all / 1e9, "peak": 8000.0, "unit": "GB/s",
-                               "frac": alg / t_all / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                               "kernel": "k_iter8 (GN iteration: steps 7-9a), mean over ALL its launches of the timed "
-                                         "steps (both instantiations: the first launch of a level also sums H)",
-                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_all * 1e6,
+            # Concurrent engines: launches of different streams overlap, so a launch's wall-clock duration is not the
+            # machine time its bytes needed. Fair share: at any moment the GPU is split evenly between the big kernels in
+            # flight (k_iter8 launches and the other stream's setup launch; the tails are 3 us each and ignored), so a
+            # launch is charged the integral of 1 / (number of kernels in flight) over its interval, and
+            #   achieved = all algorithmic bytes of the timed k_iter8 launches / machine time charged to k_iter8.
+            # With one stream nothing overlaps and this is exactly bytes per launch / mean launch duration.
+            charged = 0.0
+            if intervals:
+                evs = []
+                for x, y in intervals:
+                    evs += [(x, 1, 0), (y, -1, 0)]
+                for x, y in other_intervals:
+                    evs += [(x, 0, 1), (y, 0, -1)]
+                evs.sort()
+                n_it = n_ot = 0
+                t_prev = evs[0][0]
+                for t, di, do in evs:
+                    if n_it > 0:
+                        charged += (t - t_prev) * n_it / (n_it + n_ot)
+                    t_prev = t
+                    n_it += di
+                    n_ot += do
+            n_iv = max(len(intervals), 1)
+            t_fair = charged * 1e-3 / n_iv if (overlapping and intervals) else t_all   # s per launch, fair share
+            busy = charged
+            out["roofline"] = {"bound": "hbm", "achieved": alg / t_fair / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": alg / t_fair / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                               "kernel": "k_iter8 (GN iteration: steps 7-9a), ALL its launches of the timed steps "
+                                         "(both instantiations: the first launch of a level also sums H)",
+                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_fair * 1e6,
                                "launches_timed": n_all,
-                               "regular_launch_us": t_kernel * 1e6, "regular_launch_frac": alg / t_kernel / 1e9 / 8000.0,
-                               "first_iteration_launch_us": t_first * 1e6,
-                               "note": ("launches of different engines overlap on the GPU: the durations are wall-clock "
-                                        "durations of launches that share the machine, not solo durations"
-                                        if (tracker is not None and len(engines) > 1) else None),
+                               "duration_basis": ("fair share: every launch is charged the integral of 1 / (kernels in "
+                                                  "flight) over its interval (HIP events of all k_iter8 and setup "
+                                                  "launches of both streams on a common time base)"
+                                                  if overlapping else "mean launch duration (HIP events around each launch)"),
+                               "wall_us_per_launch": t_all * 1e6,
+                               "overlap_factor": (float(ev_kernel.sum()) / busy if (overlapping and busy > 0) else 1.0),
+                               "regular_launch_us": t_kernel * 1e6, "first_iteration_launch_us": t_first * 1e6,
+                               "note": ("two engines of B/2 frame pairs run concurrently on two HIP streams: rocprofv3 "
+                                        "--stats lists the WALL duration of each half-size launch (wall_us_per_launch); "
+                                        "the roofline uses the fair-share duration" if overlapping else None),
                                "measured_stream_read_GBps": stream_gbps.value,
-                               "frac_of_measured_stream_read": alg / t_all / 1e9 / max(stream_gbps.value, 1e-9),
+                               "frac_of_measured_stream_read": alg / t_fair / 1e9 / max(stream_gbps.value, 1e-9),
                                "per_level_kernel_us": per_level_all,
                                "per_level_bytes_unique_per_px": uniq_bpp,
-                               "per_level_unique_GBps": [b_ * pix_per_iter * pairs_per_launch / (u * 1e-6) / 1e9 if u > 0 else None
-                                                         for b_, u in zip(uniq_bpp, per_level_all)],
+                               "per_level_unique_GBps": ([b_ * pix_per_iter * pairs_per_launch / (u * 1e-6) / 1e9 if u > 0 else None
+                                                          for b_, u in zip(uniq_bpp, per_level_all)] if not overlapping else None),
                                "per_level_regular_kernel_us":
                                    [float(x - y) / max(args.steps * n_eng_step * (args.maxiter - 1), 1) * 1e3
                                     for x, y in zip(ev_kernel, ev_first)],
                                "per_level_us_per_iteration_incl_tail_and_gaps":
-                                   [float(x) / nl * 1e3 for x in ev_iters] if tracker is None else None,
+                                   [float(x) / nl * 1e3 for x in ev_iters] if not sharded else None,
                                "per_level_setup_us":
-                                   [float(x) / args.steps * 1e3 for x in ev_setup] if tracker is None else None}
+                                   [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_setup] if not sharded else None}
         pose_fail = False
         if args.cpu_seconds > 0 and world == 1 and not sharded:
             # the same tracking on the CPU path (the oracle: checker and baseline, never the product): problem 0 is
@@ -560,7 +615,7 @@ def main():
             out["pose_err_vs_cpu"] = None
         if args.secondary and world == 1 and not sharded:
             import gc as _gc
-            del engines, tracker
+            holders = tracker = None
             _gc.collect()
             from tools import secondary as sec
             out["secondary"] = sec.run_all(args.secondary_seconds)

@@ -235,6 +235,13 @@ int ictr_batch_get_level_times(ictr_batch *b, float *ms_setup, float *ms_iters);
 int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel);
 /* ms per level of the level's FIRST accumulate launch alone (8x8 fast path: the instantiation that also sums H) */
 int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first);
+/* For callers that run several engines concurrently on different streams: ictr_timebase_mark() sets a process-wide
+ * time base (synchronises the device); ictr_batch_get_kernel_intervals returns, for the last completed tracking,
+ * start and end of every accumulate launch in ms since that base, indexed [level * max(1, maxiter) + iteration]
+ * (0, 0 for launches that did not run). Overlapping intervals of different engines = launches that shared the GPU. */
+int ictr_timebase_mark(void);
+int ictr_batch_get_kernel_intervals(ictr_batch *b, float *start_ms, float *end_ms);
+int ictr_batch_get_setup_intervals(ictr_batch *b, float *start_ms, float *end_ms); /* [level]: the setup launches */
 /* which launch form the last tracking used: 0 = per-iteration launches (large problems), 1 = the one-launch tracker
  * (whole odometer.cpp:257-426 loop in one kernel, one workgroup per problem; chosen for small problems) */
 int ictr_batch_last_path(const ictr_batch *b);

@@ -4,6 +4,7 @@ importing this package never touches the GPU and never falls back to a CPU imple
 from . import _lib  # noqa: F401
 from ._lib import IctrError  # noqa: F401
 from .tracker import (CamClass, OdometerClass, PoseClass, Pyramid, TrackBatch, device_count, ncc_score, optparam,  # noqa: F401
+                      timebase_mark,
                       solve6,
                       util_constructpyramide, util_getPatch, util_getPatch_grad, util_SE3_coeff_to_group,
                       util_SE3_group_to_coeff)

@@ -119,6 +119,9 @@ SIGNATURES = {
     "ictr_batch_get_kernel_times": (C.c_int, [VP, FP]),
     "ictr_batch_get_first_iter_times": (C.c_int, [VP, FP]),
     "ictr_batch_last_path": (C.c_int, [VP]),
+    "ictr_timebase_mark": (C.c_int, []),
+    "ictr_batch_get_kernel_intervals": (C.c_int, [VP, FP, FP]),
+    "ictr_batch_get_setup_intervals": (C.c_int, [VP, FP, FP]),
     "ictr_batch_set_reduction_buffer": (C.c_int, [VP, VP]),
     "ictr_batch_enable_sharding": (C.c_int, [VP, C.c_int]),
     "ictr_batch_reduction_buffer": (VP, [VP]),

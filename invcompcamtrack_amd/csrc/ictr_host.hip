@@ -1160,6 +1160,47 @@ extern "C" int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first) {
   }
   return ICTR_OK;
 }
+// Absolute launch intervals (for callers that run several engines concurrently on different streams and need to know
+// which launches overlapped): ms since the process-wide time base set by ictr_timebase_mark().
+static hipEvent_t g_timebase = nullptr;
+extern "C" int ictr_timebase_mark(void) {
+  if (int rc = need_device()) return rc;
+  if (!g_timebase) HIPCHK(hipEventCreate(&g_timebase));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventRecord(g_timebase, nullptr));
+  HIPCHK(hipEventSynchronize(g_timebase));
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_get_kernel_intervals(ictr_batch *b, float *start_ms, float *end_ms) {
+  if (!b || !start_ms || !end_ms) return fail(ICTR_ERR_INVALID, "get_kernel_intervals: NULL argument");
+  if (b->evk.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
+  if (!g_timebase) return fail(ICTR_ERR_STATE, "ictr_timebase_mark has not been called");
+  if (int rc = batch_wait(b)) return rc;
+  const int mi = std::min(b->op->maxiter, b->evk_iters);
+  for (int l = 0; l < b->nlev; ++l)
+    for (int it = 0; it < b->evk_iters; ++it) {
+      const int k = l * b->evk_iters + it;
+      start_ms[k] = end_ms[k] = 0.0f;
+      if (!b->ev_used[l] || it >= mi) continue;
+      HIPCHK(hipEventElapsedTime(&start_ms[k], g_timebase, b->evk[2 * k]));
+      HIPCHK(hipEventElapsedTime(&end_ms[k], g_timebase, b->evk[2 * k + 1]));
+    }
+  return ICTR_OK;
+}
+// the same for the per-level setup launches (k_ref* + k_level_tail): [level]
+extern "C" int ictr_batch_get_setup_intervals(ictr_batch *b, float *start_ms, float *end_ms) {
+  if (!b || !start_ms || !end_ms) return fail(ICTR_ERR_INVALID, "get_setup_intervals: NULL argument");
+  if (b->ev.empty()) return fail(ICTR_ERR_STATE, "timing was never enabled");
+  if (!g_timebase) return fail(ICTR_ERR_STATE, "ictr_timebase_mark has not been called");
+  if (int rc = batch_wait(b)) return rc;
+  for (int l = 0; l < b->nlev; ++l) {
+    start_ms[l] = end_ms[l] = 0.0f;
+    if (b->ev_used[l] != 1) continue;
+    HIPCHK(hipEventElapsedTime(&start_ms[l], g_timebase, b->ev[3 * l + 0]));
+    HIPCHK(hipEventElapsedTime(&end_ms[l], g_timebase, b->ev[3 * l + 1]));
+  }
+  return ICTR_OK;
+}
 extern "C" int ictr_batch_last_path(const ictr_batch *b) { return b ? b->last_path : -1; }
 extern "C" int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");

@@ -20,11 +20,16 @@ from ._lib import OptParam, TraceRec, check, dp, f32c, f64c, fp
 
 __all__ = ["optparam", "CamClass", "PoseClass", "OdometerClass", "Pyramid", "TrackBatch",
            "util_constructpyramide", "util_getPatch", "util_getPatch_grad", "ncc_score", "util_SE3_coeff_to_group",
-           "util_SE3_group_to_coeff", "solve6", "device_count"]
+           "util_SE3_group_to_coeff", "solve6", "device_count", "timebase_mark"]
 
 
 def device_count():
     return _lib.load().ictr_device_count()
+
+
+def timebase_mark():
+    """Set the process-wide time base of TrackBatch.kernel_intervals (synchronises the device)."""
+    check(_lib.load().ictr_timebase_mark())
 
 
 def optparam(lv_f, lv_l, psz, maxiter, normdp_ratio, donorm, dopatchnorm, maxpttrack, verbosity=0):
@@ -421,6 +426,21 @@ class TrackBatch:
         a = np.zeros(self.op.lv_f + 1, np.float32)
         check(_lib.load().ictr_batch_get_first_iter_times(self._h, fp(a)))
         return a
+
+    def kernel_intervals(self):
+        """(start_ms, end_ms), each [levels, max(1, maxiter)], of the accumulate launches of the last tracking, in ms
+        since ``timebase_mark()``; zeros for launches that did not run."""
+        n, m = self.op.lv_f + 1, max(1, self.op.maxiter)
+        a, b = np.zeros(n * m, np.float32), np.zeros(n * m, np.float32)
+        check(_lib.load().ictr_batch_get_kernel_intervals(self._h, fp(a), fp(b)))
+        return a.reshape(n, m), b.reshape(n, m)
+
+    def setup_intervals(self):
+        """(start_ms, end_ms) per level of the setup launches of the last tracking, same time base."""
+        n = self.op.lv_f + 1
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        check(_lib.load().ictr_batch_get_setup_intervals(self._h, fp(a), fp(b)))
+        return a, b
 
     def path_name(self):
         """Launch form of the last tracking: per-iteration launches or the one-launch small-problem tracker."""
