@@ -540,7 +540,7 @@ def main():
                     continue
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts and not overlapping:
+                    if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts:
                         traffic = tj.get("hbm_bytes_per_launch_mean")
                         traffic_source = (f"profiles/{tname}: rocprofv3 --pmc passes of this command collected in "
                                           "their own runs (FETCH_SIZE x 2 + WRITE_SIZE); static, NOT measured in this run")

@@ -445,15 +445,56 @@ __global__ __launch_bounds__(64) void k_iter_finish(EngineDev e, int level, int 
 // fabric. Needs a grid that is a multiple of 8 (the launchers round up; surplus workgroups find no chunk).
 __device__ __forceinline__ int xcd_band_block(int bx, int gx) { return (gx & 7) ? bx : (bx & 7) * (gx >> 3) + (bx >> 3); }
 
-template <int kU>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1))) *gconst_f32x4;
+
+// Packed taps: the setup kernel gathers the SAME 9x9 window from three planes. With the planes interleaved as one
+// {img, dx, dy, 0} texel per pixel a window row is 144 contiguous bytes (2 cache lines) instead of 3 x 36 bytes in
+// 3-6 lines, and two 16-byte loads per lane replace three 8-byte ones. Measured reason: the three separate gathers
+// pulled ~7 KB of lines per patch through an L1 that cannot hold the 20 waves' windows, and the kernel ran at the
+// L2's pace, not HBM's (ablations in profiles/r01_notes.md).
+struct TapLoads4 {
+  f32x4_t l, r, tl, tr;  // texels at (x-1, y), (x, y) and, for lanes 0-7, the row above
+};
+__device__ __forceinline__ TapLoads4 taps_issue4(gconst_f32x4 pack_at_base, int loff, int sw, int lane) {
+  TapLoads4 t;
+  t.l = pack_at_base[loff - 1];
+  t.r = pack_at_base[loff];
+  f32x4_t z = {0.0f, 0.0f, 0.0f, 0.0f};
+  t.tl = z;
+  t.tr = z;
+  if (lane < 8) {
+    t.tl = pack_at_base[loff - sw - 1];
+    t.tr = pack_at_base[loff - sw];
+  }
+  return t;
+}
+// same operand order as taps_blend (utilities.cpp:107), plane k of the texels
+__device__ __forceinline__ float taps_blend4(const TapLoads4 &t, int k, float w0, float w1, float w2, float w3, int lane) {
+  const float a = t.r[k], b = t.l[k];
+  const float cu = __shfl_up(a, 8, 64), du = __shfl_up(b, 8, 64);
+  const float c = lane < 8 ? t.tr[k] : cu, d = lane < 8 ? t.tl[k] : du;
+  return w0 * a + w1 * b + w2 * c + w3 * d;
+}
+
+template <int kU, bool RG = false>
 struct PatchLoads {  // raw load results of one stage-2 step of kU patches (consumers belong to the reduce phase)
   float t[kU], gx[kU], gy[kU];
   TapLoads cur[kU];
+  TapLoads4 p4[RG ? kU : 1];  // RG: the packed reference window instead of the stored patch
+  int visr[RG ? kU : 1];      // RG: the point is inside the reference view at this level (else: stored patch)
   int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
 };
 
-template <bool PN, int kU, bool NT = true, bool WH = false>  // WH: also accumulate the 21 H sums (first launch of a level)
+// RG ("re-gather", coarse levels; an experiment that lost, kept behind variant bit 15): T/Gx/Gy are not streamed from the stored patches (12 of the 16 B per pixel, from HBM)
+// but blended again from the packed reference plane {img, dx, dy, 0}, which at levels >= 1 is small enough to live in
+// L2 / the Infinity Cache (level 2 of 1080p: 2 MB per problem) -- the same loads, weights and operand order as the
+// setup kernel, so the values are bit-identical to the stored ones. Points that are out of the reference view at this
+// level keep using their stored (stale) patches (odometer.cpp:304). The stored patches stay the product's state
+// (pat_ref_all semantics, read-back, next frame); this only changes where an iteration reads them from.
+template <bool PN, int kU, bool NT = true, bool WH = false, bool RG = false>  // WH: also accumulate the 21 H sums
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
+  constexpr int kRec = RG ? 24 : 16;  // RG: + [w0r w1r w2r w3r][base_r vis_r - -] of the reference-pose window
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartBStride];
   __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
@@ -469,6 +510,8 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   const float *__restrict__ Gy = e.Gy + (size_t)b * M * 64;
   const float *__restrict__ coefb = e.coef + (size_t)b * M * kCoefStride;
   gconst_f32 cur = (gconst_f32)pl.cur;
+  gconst_f32x4 ppack = (gconst_f32x4)pl.pack;
+  const float *__restrict__ pt2d = e.pt2d + ((size_t)b * e.nlev + level) * 2 * M;
   const int sw = lc.sw;
 
   float G[12];
@@ -506,12 +549,21 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
     const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
     const int base_v = tp.row0 * sw + tp.col0;
+    int baser_v = 0, visr_v = 0;
     {
       float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
       r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
       r4[1] = make_float4(q0.x, q0.z, q0.w, q1.x);
       r4[2] = make_float4(q1.y, q1.w, q2.x, q2.y);
       r4[3] = make_float4(q2.z, q2.w, vis ? 1.0f : 0.0f, 0.0f);
+      if constexpr (RG) {  // the reference-pose window of the point at this level (odometer.cpp:268-286), as in k_ref8
+        const float mxr = pt2d[ip], myr = pt2d[ip + M];
+        const bool visr = pv && in_view(mxr, myr, lc.swo, lc.sho);
+        const Taps tr = make_taps(visr ? mxr : 1.0f, visr ? myr : 1.0f, 4);
+        baser_v = tr.row0 * sw + tr.col0;
+        visr_v = visr ? 1 : 0;
+        r4[4] = make_float4(tr.w0, tr.w1, tr.w2, tr.w3);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -519,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
 
     // ---- stage 2. The kU patches of a step are nsteps apart (neighbouring points share frame cache lines).
     const int nsteps = (cnt + kU - 1) / kU;
-    auto issue = [&](PatchLoads<kU> &L, int sidx) {
+    auto issue = [&](PatchLoads<kU, RG> &L, int sidx) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int jraw = sidx + u * nsteps;
@@ -527,7 +579,17 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         L.rec[u] = (jraw < cnt) ? jj : -1;
         const int base = rlane(base_v, jj);
         const size_t po = (size_t)(i0 + jj) * 64;  // wave-uniform: scalar base + 32-bit lane offset
-        if constexpr (NT) {  // streamed once per launch: keep them from evicting the (re-used) frame lines
+        bool stored = true;
+        if constexpr (RG) {
+          L.visr[u] = rlane(visr_v, jj);
+          if (L.visr[u]) {  // wave-uniform
+            L.p4[u] = taps_issue4(ppack + rlane(baser_v, jj), loff, sw, lane);
+            stored = false;
+          }
+        }
+        if (!stored) {
+          L.t[u] = L.gx[u] = L.gy[u] = 0.0f;
+        } else if constexpr (NT) {  // streamed once per launch: keep them from evicting the (re-used) frame lines
           L.t[u] = __builtin_nontemporal_load(T + po + lane);
           L.gx[u] = __builtin_nontemporal_load(Gx + po + lane);
           L.gy[u] = __builtin_nontemporal_load(Gy + po + lane);
@@ -539,16 +601,26 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         L.cur[u] = taps_issue(cur + base, loff, sw, lane);
       }
     };
-    auto reduce = [&](const PatchLoads<kU> &L) {
+    auto reduce = [&](const PatchLoads<kU, RG> &L) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (L.rec[u] < 0) continue;  // wave-uniform
-        const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
-                     k2 = rec4[L.rec[u] * 4 + 3];
+        constexpr int R4 = kRec / 4;
+        const float4 w = rec4[L.rec[u] * R4 + 0], k0 = rec4[L.rec[u] * R4 + 1], k1 = rec4[L.rec[u] * R4 + 2],
+                     k2 = rec4[L.rec[u] * R4 + 3];
         float inew = taps_blend(L.cur[u], w.x, w.y, w.z, w.w, lane);
         if constexpr (PN) inew -= wave_sum(inew) / 64.0f;  // utilities.cpp:111-112
-        const float r = (L.t[u] - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 for points out of view
-        const float gx = L.gx[u], gy = L.gy[u];
+        float tv = L.t[u], gx = L.gx[u], gy = L.gy[u];
+        if constexpr (RG) {
+          if (L.visr[u]) {  // utilities.cpp:115-189 again, from the cache-resident packed plane (bit-identical values)
+            const float4 wr = rec4[L.rec[u] * R4 + 4];
+            tv = taps_blend4(L.p4[u], 0, wr.x, wr.y, wr.z, wr.w, lane);
+            gx = taps_blend4(L.p4[u], 1, wr.x, wr.y, wr.z, wr.w, lane);
+            gy = taps_blend4(L.p4[u], 2, wr.x, wr.y, wr.z, wr.w, lane);
+            if constexpr (PN) tv -= wave_sum(tv) / 64.0f;  // utilities.cpp:187-188
+          }
+        }
+        const float r = (tv - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 for points out of view
         {
 #pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only: FMA allowed from here on
           acc[0] += (gx * k0.x) * r;              // sd1 = Gx cx0
@@ -574,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         }
       }
     };
-    PatchLoads<kU> A, B;
+    PatchLoads<kU, RG> A, B;
     issue(A, 0);
     for (int sidx = 0; sidx < nsteps; sidx += 2) {
       if (sidx + 1 < nsteps) issue(B, sidx + 1);
@@ -613,38 +685,6 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
 // steps 4-6 for 8x8 patches, same two-stage, software-pipelined form (reference patches + gradients, sd
 // coefficients, H partials). The patches T/Gx/Gy it stores are bit-exact (un-contracted blends); only the 21 H sums,
 // which are compared to tolerance, use FMA.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef const f32x4_t __attribute__((address_space(1))) *gconst_f32x4;
-
-// Packed taps: the setup kernel gathers the SAME 9x9 window from three planes. With the planes interleaved as one
-// {img, dx, dy, 0} texel per pixel a window row is 144 contiguous bytes (2 cache lines) instead of 3 x 36 bytes in
-// 3-6 lines, and two 16-byte loads per lane replace three 8-byte ones. Measured reason: the three separate gathers
-// pulled ~7 KB of lines per patch through an L1 that cannot hold the 20 waves' windows, and the kernel ran at the
-// L2's pace, not HBM's (ablations in profiles/r01_notes.md).
-struct TapLoads4 {
-  f32x4_t l, r, tl, tr;  // texels at (x-1, y), (x, y) and, for lanes 0-7, the row above
-};
-__device__ __forceinline__ TapLoads4 taps_issue4(gconst_f32x4 pack_at_base, int loff, int sw, int lane) {
-  TapLoads4 t;
-  t.l = pack_at_base[loff - 1];
-  t.r = pack_at_base[loff];
-  f32x4_t z = {0.0f, 0.0f, 0.0f, 0.0f};
-  t.tl = z;
-  t.tr = z;
-  if (lane < 8) {
-    t.tl = pack_at_base[loff - sw - 1];
-    t.tr = pack_at_base[loff - sw];
-  }
-  return t;
-}
-// same operand order as taps_blend (utilities.cpp:107), plane k of the texels
-__device__ __forceinline__ float taps_blend4(const TapLoads4 &t, int k, float w0, float w1, float w2, float w3, int lane) {
-  const float a = t.r[k], b = t.l[k];
-  const float cu = __shfl_up(a, 8, 64), du = __shfl_up(b, 8, 64);
-  const float c = lane < 8 ? t.tr[k] : cu, d = lane < 8 ? t.tl[k] : du;
-  return w0 * a + w1 * b + w2 * c + w3 * d;
-}
-
 template <int kU>
 struct RefLoads {
   TapLoads r[kU], x[kU], y[kU];
@@ -1458,6 +1498,15 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
         hipLaunchKernelGGL((k_iter8<false, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
       else
         hipLaunchKernelGGL((k_iter8<false, 4, true, true>), g8, blk, 0, s, e, lc, level, cpw);
+    } else if (e.packed && level >= 1 && (variant & 32768)) {
+      // experiment (variant bit 15, off by default): at coarse levels re-gather T/Gx/Gy from the cache-resident packed
+      // reference plane (k_iter8<.., RG = true>). Measured r02: 331 / 279 us per launch at levels 1 / 2 against
+      // 195 / 182 for the stored patches -- three more blends, 8 ds_bpermute and 167 VGPRs per patch cost more than
+      // the 0.8 GB of HBM reads they save (profiles/r02_notes.md)
+      if (e.dopatchnorm)
+        hipLaunchKernelGGL((k_iter8<true, 2, true, false, true>), g8, blk, 0, s, e, lc, level, cpw);
+      else
+        hipLaunchKernelGGL((k_iter8<false, 2, true, false, true>), g8, blk, 0, s, e, lc, level, cpw);
     } else if (e.dopatchnorm)
       hipLaunchKernelGGL((k_iter8<true, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
