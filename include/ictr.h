@@ -263,6 +263,19 @@ int ictr_batch_level_finish(ictr_batch *b, int level);      /* adopt (reduced) H
 int ictr_batch_iter_accumulate(ictr_batch *b, int level);   /* steps 7-9a -> local b in red[] */
 int ictr_batch_iter_finish(ictr_batch *b, int level);       /* steps 9b-10 on the (reduced) b */
 
+/* ------------------------------------------------------------------ Python flow-tracking surface on the device
+ * misc_src/classoftrack.py:4-34 func_get_transf_position: K points (x, y) moved by a displacement field sampled
+ * bilinearly at the points; float64 arithmetic in NumPy's operation order (bit-identical to the NumPy restatement and
+ * to the goldens generated from the reference); NaN for points whose four taps are not all inside the field.
+ * disp_u / disp_v: (H, W) planes, float32 (is_f64 = 0) or float64, host or device pointers (fields_on_device);
+ * disp_v may be NULL (x only). xy and out: host (K, 2) float64. */
+int ictr_flow_gather(const void *disp_u, const void *disp_v, int is_f64, int fields_on_device, int H, int W,
+                     const double *xy, int64_t K, double *out);
+/* misc_src/func_OF_util.py:87-129 func_extract_bil_patch, batched and without the post-processing options: K raw
+ * bilinear patches (side x side x C, side = 2 (pz / 2): Python-2 integer division) of a host (H, W, C) float64 image
+ * around host points (K, 2) float64; out: host (K, side, side, C) float64. Windows must lie inside the image. */
+int ictr_extract_bil_patches(const double *img, int H, int W, int C, const double *pts, int64_t K, int pz, double *out);
+
 /* ---- one-shot peer-to-peer all-reduce of the reduction buffer (latency-optimal on point-to-point xGMI) ----
  * Each rank stores its nproblems*27 floats straight into a mailbox slot in every peer's device memory (mapped with
  * hipIpc) and adds the world slots of its own mailbox in rank order: one hop instead of a ring's 2(N-1), one small

@@ -131,6 +131,8 @@ SIGNATURES = {
     "ictr_batch_level_finish": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_accumulate": (C.c_int, [VP, C.c_int]),
     "ictr_batch_iter_finish": (C.c_int, [VP, C.c_int]),
+    "ictr_flow_gather": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, DP, I64, DP]),
+    "ictr_extract_bil_patches": (C.c_int, [DP, C.c_int, C.c_int, C.c_int, DP, I64, C.c_int, DP]),
     "ictr_p2p_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, I64]),
     "ictr_p2p_handle_bytes": (C.c_int, []),
     "ictr_p2p_local_handle": (C.c_int, [VP, VP]),

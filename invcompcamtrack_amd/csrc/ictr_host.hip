@@ -25,6 +25,8 @@ void launch_getpatch(const float *, const float *, const float *, const float *,
                      float *, hipStream_t);
 void launch_ncc(const float *, const float *, const float *, const float *, int, int, int, float, float, float, float,
                 float *, hipStream_t);
+void launch_flow_gather(const void *, const void *, int, int, int, const double *, int, double *, hipStream_t);
+void launch_bil_patches(const double *, int, int, int, const double *, int, int, double *, hipStream_t);
 void launch_project_generic(const float *, float *, float *, int, int, const float *, LevelCam, hipStream_t);
 void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
 void launch_ref_level(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
@@ -503,6 +505,69 @@ extern "C" int ictr_ncc_score(const ictr_pyramid *pyr_back, const ictr_pyramid *
   }
   hipFree(d);
   if (e != hipSuccess) return fail(ICTR_ERR_HIP, "ncc_score failed: %s", hipGetErrorString(e));
+  return ICTR_OK;
+}
+
+// ---------------------------------------------------------------- Python flow-tracking surface (misc_src) on the device
+// classoftrack.func_get_transf_position (classoftrack.py:4-34). disp_u / disp_v: (H, W) planes, float32 or float64,
+// on the host or (fields_on_device) already on the device; disp_v may be NULL. xy, out: host (K, 2) float64.
+extern "C" int ictr_flow_gather(const void *disp_u, const void *disp_v, int is_f64, int fields_on_device, int H, int W,
+                                const double *xy, int64_t K, double *out) {
+  if (!disp_u || H < 1 || W < 1 || K < 0 || (K > 0 && (!xy || !out)))
+    return fail(ICTR_ERR_INVALID, "flow_gather: bad arguments");
+  if (K == 0) return ICTR_OK;
+  if (int rc = need_device()) return rc;
+  const size_t fb = (size_t)H * W * (is_f64 ? 8 : 4);
+  char *d_f = nullptr;
+  double *d_xy = nullptr;
+  hipError_t e = hipMalloc((void **)&d_xy, sizeof(double) * 4 * K);
+  const void *du = disp_u, *dv = disp_v;
+  if (e == hipSuccess && !fields_on_device) {
+    e = hipMalloc((void **)&d_f, fb * 2);
+    if (e == hipSuccess) e = hipMemcpy(d_f, disp_u, fb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && disp_v) e = hipMemcpy(d_f + fb, disp_v, fb, hipMemcpyHostToDevice);
+    du = d_f;
+    dv = disp_v ? d_f + fb : nullptr;
+  }
+  if (e == hipSuccess) e = hipMemcpy(d_xy, xy, sizeof(double) * 2 * K, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_flow_gather(du, dv, is_f64, H, W, d_xy, (int)K, d_xy + 2 * K, nullptr);
+    e = hipMemcpy(out, d_xy + 2 * K, sizeof(double) * 2 * K, hipMemcpyDeviceToHost);
+  }
+  if (d_f) hipFree(d_f);
+  if (d_xy) hipFree(d_xy);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "flow_gather failed: %s", hipGetErrorString(e));
+  return ICTR_OK;
+}
+
+// func_OF_util.func_extract_bil_patch (func_OF_util.py:87-129), batched: img host (H, W, C) float64, pts host (K, 2)
+// float64 (x, y), out host (K, side, side, C) float64 with side = 2 (pz / 2). Every window must lie inside the image.
+extern "C" int ictr_extract_bil_patches(const double *img, int H, int W, int C, const double *pts, int64_t K, int pz,
+                                        double *out) {
+  const int half = pz / 2;
+  if (!img || H < 2 || W < 2 || C < 1 || K < 0 || pz < 2 || (K > 0 && (!pts || !out)))
+    return fail(ICTR_ERR_INVALID, "extract_bil_patches: bad arguments");
+  for (int64_t k = 0; k < K; ++k) {
+    const double fx = floor(pts[2 * k]), fy = floor(pts[2 * k + 1]);
+    if (!(fx - half >= 0 && fy - half >= 0 && fx + half < W && fy + half < H))  // taps x0 .. x0 + side (ceil window)
+      return fail(ICTR_ERR_INVALID, "extract_bil_patches: the window of point %lld leaves the image", (long long)k);
+  }
+  if (K == 0) return ICTR_OK;
+  if (int rc = need_device()) return rc;
+  const size_t ib = sizeof(double) * (size_t)H * W * C, ob = sizeof(double) * (size_t)K * 4 * half * half * C;
+  double *d_img = nullptr, *d_pts = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc((void **)&d_img, ib);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_pts, sizeof(double) * 2 * K);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, ob);
+  if (e == hipSuccess) e = hipMemcpy(d_img, img, ib, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_pts, pts, sizeof(double) * 2 * K, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_bil_patches(d_img, H, W, C, d_pts, (int)K, half, d_out, nullptr);
+    e = hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost);
+  }
+  for (void *p_ : {(void *)d_img, (void *)d_pts, (void *)d_out})
+    if (p_) hipFree(p_);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "extract_bil_patches failed: %s", hipGetErrorString(e));
   return ICTR_OK;
 }
 

@@ -1287,6 +1287,72 @@ void launch_ncc(const float *img_b, const float *img_r, const float *img_f, cons
     hipLaunchKernelGGL((k_ncc<64>), dim3(gx), dim3(kBlock), 0, s, fb, fr, ff, mids, K, P, sw, swo, sho, w_back, w_fwd, out);
 }
 
+// ---------------------------------------------------------------- Python flow-tracking surface on the device
+// func_get_transf_position (misc_src/classoftrack.py:4-34): K sub-pixel points moved by a displacement field sampled
+// bilinearly at the points, in float64 with NumPy's operation order (field value widened, times weight, summed left
+// to right), so the result is bit-identical to the NumPy restatement and to the reference's goldens. A point whose four
+// taps are not all inside the field comes back as NaN. F = float or double (the field's dtype).
+template <typename F>
+__global__ __launch_bounds__(kBlock) void k_flow_gather(const F *__restrict__ du, const F *__restrict__ dv, int H, int W,
+                                                        const double *__restrict__ xy, int K, double *__restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= K) return;
+  const double x = xy[2 * i], y = xy[2 * i + 1];
+  const double flx = floor(x), fly = floor(y);
+  const double nan = __builtin_nan("");
+  double ox = nan, oy = nan;
+  // NaN / out-of-range coordinates fail the range test (written positively), like the INT_MIN cast in NumPy
+  if (flx >= 0.0 && fly >= 0.0 && flx + 1.0 < (double)W && fly + 1.0 < (double)H) {
+    const int x0 = (int)flx, y0 = (int)fly, x1 = x0 + 1, y1 = y0 + 1;
+    const double fx = x - flx, fy = y - fly;
+    const double w0 = fx * fy, w1 = (1 - fx) * fy, w2 = fx * (1 - fy), w3 = (1 - fx) * (1 - fy);
+    const size_t a = (size_t)y1 * W + x1, b = (size_t)y1 * W + x0, c = (size_t)y0 * W + x1, d = (size_t)y0 * W + x0;
+    ox = x + ((double)du[a] * w0 + (double)du[b] * w1 + (double)du[c] * w2 + (double)du[d] * w3);
+    oy = y;
+    if (dv) oy = y + ((double)dv[a] * w0 + (double)dv[b] * w1 + (double)dv[c] * w2 + (double)dv[d] * w3);
+  }
+  out[2 * i] = ox;
+  out[2 * i + 1] = oy;
+}
+void launch_flow_gather(const void *du, const void *dv, int is_f64, int H, int W, const double *xy, int K, double *out,
+                        hipStream_t s) {
+  const dim3 g((K + kBlock - 1) / kBlock), blk(kBlock);
+  if (is_f64)
+    hipLaunchKernelGGL((k_flow_gather<double>), g, blk, 0, s, (const double *)du, (const double *)dv, H, W, xy, K, out);
+  else
+    hipLaunchKernelGGL((k_flow_gather<float>), g, blk, 0, s, (const float *)du, (const float *)dv, H, W, xy, K, out);
+}
+
+// func_extract_bil_patch (misc_src/func_OF_util.py:87-129), batched: K points, raw (side x side x C) bilinear patches
+// of an (H, W, C) float64 image, side = 2 (pz / 2) (Python-2 integer division), patch-constant weights on four
+// integer-shifted windows in NumPy's operation order. One thread per output value; windows that leave the image are
+// the caller's error (checked on the host).
+__global__ __launch_bounds__(kBlock) void k_bil_patches(const double *__restrict__ img, int H, int W, int C,
+                                                        const double *__restrict__ pts, int K, int half,
+                                                        double *__restrict__ out) {
+  const int side = 2 * half;
+  const size_t per = (size_t)side * side * C;
+  const size_t n = (size_t)K * per;
+  for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (size_t)gridDim.x * kBlock) {
+    const int k = (int)(t / per);
+    const size_t r = t - (size_t)k * per;
+    const int c = (int)(r % C), px = (int)((r / C) % side), py = (int)(r / ((size_t)C * side));
+    const double x = pts[2 * k], y = pts[2 * k + 1];
+    const double flx = floor(x), fly = floor(y);
+    const double fx = x - flx, fy = y - fly;
+    const int x0 = (int)flx - half + px, y0 = (int)fly - half + py;
+    const double a = img[((size_t)(y0 + 1) * W + (x0 + 1)) * C + c], b = img[((size_t)(y0 + 1) * W + x0) * C + c];
+    const double cc = img[((size_t)y0 * W + (x0 + 1)) * C + c], d = img[((size_t)y0 * W + x0) * C + c];
+    out[t] = a * (fx * fy) + b * ((1 - fx) * fy) + cc * (fx * (1 - fy)) + d * ((1 - fx) * (1 - fy));
+  }
+}
+void launch_bil_patches(const double *img, int H, int W, int C, const double *pts, int K, int half, double *out,
+                        hipStream_t s) {
+  const size_t n = (size_t)K * 4 * half * half * C;
+  const int g = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192);
+  hipLaunchKernelGGL(k_bil_patches, dim3(std::max(g, 1)), dim3(kBlock), 0, s, img, H, W, C, pts, K, half, out);
+}
+
 // ---------------------------------------------------------------- pyramid (utilities.cpp:14-52)
 // level 0: copy the w x h image into the interior of the padded plane
 __global__ __launch_bounds__(kBlock) void k_pyr_copy(const float *__restrict__ src, float *dst, int w, int h, int pad,

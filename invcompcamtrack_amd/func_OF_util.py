@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["func_eval_flowgt", "func_read_flo_file", "func_write_flo_file", "func_read_pfm_file",
+__all__ = ["func_extract_bil_patches_hip", "func_eval_flowgt", "func_read_flo_file", "func_write_flo_file", "func_read_pfm_file",
            "func_extract_bil_patch", "func_extract_NN_patch", "func_get_pat_cosmask", "gauss2Dfilter"]
 
 FLO_MAGIC = 202021.25  # Middlebury .flo tag ("PIEH" as float32)
@@ -122,6 +122,23 @@ def func_extract_bil_patch(ptin, img, pz, do_zeromean=0, use_mask=None, do_log=0
     pf = (window(1, 1) * (fx * fy) + window(1, 0) * ((1 - fx) * fy)
           + window(0, 1) * (fx * (1 - fy)) + window(0, 0) * ((1 - fx) * (1 - fy)))
     return _postprocess(pf, do_zeromean, use_mask, do_log, do_unitnorm, do_flatten)
+
+
+def func_extract_bil_patches_hip(pts, img, pz):
+    """Batched raw ``func_extract_bil_patch`` on the device (``ictr_extract_bil_patches``): pts (K, 2) -> patches
+    (K, side, side, C), side = 2 * (pz // 2), bit-identical to ``func_extract_bil_patch(pt, img, pz, do_flatten=0)``
+    for every point (float64, same operation order). The post-processing options (log / zero-mean / mask / unit norm /
+    flatten) stay per patch in ``_postprocess``. No CPU fallback: raises IctrError without a GPU."""
+    from . import _lib
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    if img.ndim != 3:
+        raise ValueError("img must be (H, W, C)")
+    side = 2 * (pz // 2)
+    out = np.empty((pts.shape[0], side, side, img.shape[2]), np.float64)
+    _lib.check(_lib.load().ictr_extract_bil_patches(_lib.dp(img), img.shape[0], img.shape[1], img.shape[2],
+                                                    _lib.dp(pts), pts.shape[0], int(pz), _lib.dp(out)))
+    return out
 
 
 def func_extract_NN_patch(ptin, img, pz, do_zeromean=0, use_mask=None, do_log=0, do_unitnorm=0, do_flatten=1):
