@@ -1099,10 +1099,14 @@ static bool use_track1(const ictr_batch *b) {
   if (b->sharded || b->timing || (v & 8192)) return false;
   if (b->maxpts < 1 || (size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS
   if (v & 16384) return true;
-  static const int limit = [] {
+  // Measured (tools/latency.py, r02): one problem costs 0.17 ms + 1.9 us per 8x8 patch in one launch against a flat
+  // 0.52 ms of dependent launches -> cross-over near 190 points; a batch of independent problems (run_track_nposes:
+  // one workgroup per pose sample, all CUs busy) still wins at 300 points each (64 x 300: 0.87 vs 0.98 ms).
+  static const int forced = [] {
     const char *s = getenv("ICTR_TRACK1_MAXPTS");
-    return s ? atoi(s) : 1024;
+    return s ? atoi(s) : 0;
   }();
+  const int limit = forced > 0 ? forced : (b->B >= 16 ? 384 : 192);
   return (int64_t)b->maxpts * b->n <= (int64_t)limit * 64;
 }
 static int track1_waves(const ictr_batch *b) {

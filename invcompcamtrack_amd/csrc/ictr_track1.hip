@@ -595,6 +595,10 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
   __shared__ float sPart[kT1MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
   __shared__ float sG[12];                             // cpos_G of the current iteration
   __shared__ int sActive;                              // loop condition, decided by wave 0
+  // per wave, per patch of the current chunk: [w1 w0 w3 w2][vis - - -] of the current iteration. Written by the
+  // patch's own lane in stage 1, read back as broadcast ds_read_b128 in stage 2: the LDS pipe is idle there, the VALU
+  // is the bottleneck (a v_readlane per scalar cost 15 VALU slots per patch)
+  __shared__ __attribute__((aligned(16))) float sRecW[kT1MaxWaves][64 * 8];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -768,13 +772,13 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
     T1_MARK(2)  // H sum + LU
 
     // ---------------------------------------------------------------- Gauss-Newton iterations of this level
-    gconst_f32 curg = (gconst_f32)pl.cur;
+    // the current frame through a buffer descriptor: wave-uniform window base in an SGPR offset, per-lane constant
+    // byte offsets in a VGPR -> no vector address arithmetic per load
+    const __amdgpu_buffer_rsrc_t rcur =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl.cur), 0, 0x7fffffff, 0x00020000);
     const bool single = mycnt <= 64;
-    float4 q01 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q11 = q01, q21 = q01;
-    if (single) {
-      const int i1 = wave + (lane < mycnt ? lane : 0) * nwaves;  // wave >= npts: mycnt = 0, index stays in the arrays
-      q01 = lCoef[i1 * 3 + 0], q11 = lCoef[i1 * 3 + 1], q21 = lCoef[i1 * 3 + 2];
-    }
+    float *recw = sRecW[wave];
+    const float4 *recw4 = reinterpret_cast<const float4 *>(recw);
     while (sActive) {  // workgroup-uniform: read after a barrier, rewritten only between barriers
       float acc[6];
 #pragma unroll
@@ -787,14 +791,10 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
         // stage 1: projection at the current pose (pose.cpp:384-391), ind_new (odometer.cpp:369-377)
         const bool pv = lane < cn;
         const int ip = wave + (c0 + (pv ? lane : 0)) * nwaves;
-        // a wave with at most 64 points (up to 512 points per problem) keeps each point's X, Y, Z and coefficients in
-        // its lane's registers for the whole level: no memory round trip in front of the projection
+        // a wave with at most 64 points (up to 512 points per problem) keeps each point's X, Y, Z in its lane's
+        // registers for the whole tracking: no memory round trip in front of the projection
         float X = X1, Y = Y1, Z = Z1;
-        float4 q0 = q01, q1 = q11, q2 = q21;
-        if (!single) {
-          X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
-          q0 = lCoef[ip * 3 + 0], q1 = lCoef[ip * 3 + 1], q2 = lCoef[ip * 3 + 2];
-        }
+        if (!single) X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
         const float tx = Gc[0] * X + Gc[1] * Y + Gc[2] * Z + Gc[3];
         const float ty = Gc[4] * X + Gc[5] * Y + Gc[6] * Z + Gc[7];
         const float tz = Gc[8] * X + Gc[9] * Y + Gc[10] * Z + Gc[11];
@@ -802,12 +802,16 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
         const float my = (ty / tz) * lc.fy + lc.cy;
         const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
         const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
-        const int base_v = (tp.row0 - 1) * sw + tp.col0 - 1;
-        const float vis_f = vis ? 1.0f : 0.0f;
+        const int base_v = ((tp.row0 - 1) * sw + tp.col0 - 1) * 4;  // bytes: the buffer load's scalar offset
+        {
+          float4 *r4 = reinterpret_cast<float4 *>(recw + lane * 8);
+          r4[0] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
+          r4[1] = make_float4(vis ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T1_MARK(3)  // stage 1
-#ifdef ICTR_T1_PROF
-        if (dbg & 1) continue;  // ablation: no patch work at all
-#endif
         // stage 2: one patch per step, software-pipelined
         auto issue = [&](T8Loads<kU> &L, int k) {
 #pragma unroll
@@ -815,8 +819,25 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
             const bool ok = k + u < cn;
             const int kk = ok ? k + u : k;
             L.k[u] = ok ? kk : -1;
-            L.cur[u] = t8_issue(curg, rl(base_v, kk), off_cd, off_ab);
+            const int soff = rl(base_v, kk);
+#ifdef ICTR_T1_PROF
+            if (dbg & 2) {  // ablation: no current-frame loads
+              L.cur[u].cd = f32x2_a4{1.0f + lane, 2.0f};
+              L.cur[u].ab = f32x2_a4{3.0f, 4.0f + kk};
+            } else
+#endif
+            {
+              L.cur[u].cd = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_cd, soff, 0));
+              L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_ab, soff, 0));
+            }
             const int i = wave + (c0 + kk) * nwaves;
+#ifdef ICTR_T1_PROF
+            if (dbg & 4) {  // ablation: no template reads
+              L.t[u] = 100.0f + lane;
+              L.gx[u] = 1.0f;
+              L.gy[u] = 2.0f;
+            } else
+#endif
             if constexpr (TL) {
               const float *tpl = lTpl + i * 192 + lane;
               L.t[u] = tpl[0];
@@ -831,22 +852,42 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
           }
         };
         auto reduce = [&](const T8Loads<kU> &L) {
+          float4 wv[kU], q0[kU], q1[kU], q2[kU];
+          float vf[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {  // the patches' scalars: broadcast LDS reads, all in flight together
+            const int kk = L.k[u] < 0 ? 0 : L.k[u];
+            const int i = wave + (c0 + kk) * nwaves;
+#ifdef ICTR_T1_PROF
+            if (dbg & 8) {  // ablation: no per-patch scalar reads
+              wv[u] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
+              vf[u] = 1.0f;
+              q0[u] = q1[u] = q2[u] = make_float4(1e-3f, 2e-3f, 1e-3f, 3e-3f);
+              continue;
+            }
+#endif
+            wv[u] = recw4[kk * 2];
+            vf[u] = recw[kk * 8 + 4];
+            q0[u] = lCoef[i * 3 + 0];
+            q1[u] = lCoef[i * 3 + 1];
+            q2[u] = lCoef[i * 3 + 2];
+          }
 #pragma unroll
           for (int u = 0; u < kU; ++u) {
             if (L.k[u] < 0) continue;  // wave-uniform
-            const int kk = L.k[u];
-            float inew = t8_blend(L.cur[u], rl(tp.w0, kk), rl(tp.w1, kk), rl(tp.w2, kk), rl(tp.w3, kk));
+            // utilities.cpp:107 in the reference's operand order, not contracted: ((w0 a + w1 b) + w2 c) + w3 d
+            float inew = wv[u].y * L.cur[u].ab.y + wv[u].x * L.cur[u].ab.x + wv[u].w * L.cur[u].cd.y + wv[u].z * L.cur[u].cd.x;
             if constexpr (PN) inew -= wave_sum_dpp(inew) / 64.0f;  // utilities.cpp:111-112
-            const float r = (L.t[u] - inew) * rl(vis_f, kk);  // pdiff (odometer.cpp:381); 0 out of the new view
+            const float r = (L.t[u] - inew) * vf[u];  // pdiff (odometer.cpp:381); 0 out of the new view
             {
 #pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only
               const float gr = L.gx[u] * r, hr = L.gy[u] * r;
-              acc[0] += gr * rl(q0.x, kk);                       // sd1 = Gx cx0
-              acc[1] += hr * rl(q1.y, kk);                       // sd2 = Gy cy1
-              acc[2] += gr * rl(q0.y, kk) + hr * rl(q1.z, kk);   // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
-              acc[3] += gr * rl(q0.z, kk) + hr * rl(q1.w, kk);
-              acc[4] += gr * rl(q0.w, kk) + hr * rl(q2.x, kk);
-              acc[5] += gr * rl(q1.x, kk) + hr * rl(q2.y, kk);
+              acc[0] += gr * q0[u].x;                     // sd1 = Gx cx0
+              acc[1] += hr * q1[u].y;                     // sd2 = Gy cy1
+              acc[2] += gr * q0[u].y + hr * q1[u].z;      // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
+              acc[3] += gr * q0[u].z + hr * q1[u].w;
+              acc[4] += gr * q0[u].w + hr * q2[u].x;
+              acc[5] += gr * q1[u].x + hr * q2[u].y;
             }
           }
         };
@@ -858,6 +899,8 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
           if (k + 2 * kU < cn) issue(A, k + 2 * kU);
           if (k + kU < cn) reduce(B);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the records are rewritten by the next chunk
       }
       T1_MARK(4)  // stage 2 of wave 0
       T1_REDUCE_STORE(6, acc, sPart[wave])
@@ -909,7 +952,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
 size_t track1_plan(int npts_cap, int n, int p8, int *tmpl_lds) {
   const size_t recb = (size_t)npts_cap * (p8 ? 48 : 68);  // 8x8: 12 coefficient floats; else 64-byte record + base
   const size_t tmplb = (size_t)npts_cap * n * 3 * sizeof(float);
-  const size_t budget = 150 * 1024;  // of the CU's 160 KB; the static arrays take ~1 KB
+  const size_t budget = 140 * 1024;  // of the CU's 160 KB; the static arrays (sRecW, partial sums) take ~18 KB
   *tmpl_lds = (recb + tmplb <= budget) ? 1 : 0;
   return recb + (*tmpl_lds ? tmplb : 0);
 }
@@ -918,7 +961,7 @@ template <typename K>
 static hipError_t launch_t1(K kernel, size_t *granted, const EngineDev &e, const T1Args &a, int waves, size_t lds,
                             hipStream_t s) {
   if (lds > *granted) {  // dynamic LDS above 64 KB must be granted per function
-    const size_t want = 156 * 1024;
+    const size_t want = 141 * 1024;
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
     if (rc != hipSuccess) return rc;

@@ -37,12 +37,12 @@ LAUNCHES = 8192   # variant bit 13: per-iteration launch pairs (k_ref* / k_iter*
 ONE_LAUNCH = 16384  # variant bit 14: the one-launch tracker k_track1 (default choice for small problems)
 
 
-@pytest.fixture(params=["auto", "launches"])
+@pytest.fixture(params=["one_launch", "launches"])
 def launch_form(request):
-    """Every case below that takes this fixture runs twice: with the library's own choice (these problems are small,
-    so the whole tracking is ONE launch of k_track1) and with the per-iteration launch sequence forced."""
+    """Every case below that takes this fixture runs twice: as ONE launch of k_track1 (the library's own choice for
+    problems up to ~190 points, or ~380 per problem in a batch) and as the per-iteration launch sequence."""
     import parity_util
-    parity_util.FORCE_VARIANT = 0 if request.param == "auto" else LAUNCHES
+    parity_util.FORCE_VARIANT = ONE_LAUNCH if request.param == "one_launch" else LAUNCHES
     yield request.param
     parity_util.FORCE_VARIANT = 0
 
@@ -260,6 +260,7 @@ def test_one_launch_tracker_equals_per_iteration_launches(oracle, cfg):
 def test_one_launch_tracker_is_the_default_for_small_batches(oracle):
     """run_track_nposes' shape: many small independent problems = one workgroup each, one launch per frame pair;
     large problems keep the per-iteration launches."""
+    # the automatic choice: <= 192 points alone, <= 384 per problem in a batch of >= 16, else per-iteration launches
     sc = scene(320, 240, 60, seed=21)
     op = ic.optparam(2, 0, 8, 5, 0.01, 0, 0, 60)
     cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
