@@ -477,24 +477,24 @@ __device__ __forceinline__ float taps_blend4(const TapLoads4 &t, int k, float w0
   return w0 * a + w1 * b + w2 * c + w3 * d;
 }
 
-template <int kU, bool RG = false>
+template <int kU>
 struct PatchLoads {  // raw load results of one stage-2 step of kU patches (consumers belong to the reduce phase)
   float t[kU], gx[kU], gy[kU];
-  TapLoads cur[kU];
-  TapLoads4 p4[RG ? kU : 1];  // RG: the packed reference window instead of the stored patch
-  int visr[RG ? kU : 1];      // RG: the point is inside the reference view at this level (else: stored patch)
+  TapLoads cur[kU];  // LD == 2: .ab = (x-1,y),(x,y) and .top = (x-1,y-1),(x,y-1) of the lane's own pixel
   int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
 };
 
-// RG ("re-gather", coarse levels; an experiment that lost, kept behind variant bit 15): T/Gx/Gy are not streamed from the stored patches (12 of the 16 B per pixel, from HBM)
-// but blended again from the packed reference plane {img, dx, dy, 0}, which at levels >= 1 is small enough to live in
-// L2 / the Infinity Cache (level 2 of 1080p: 2 MB per problem) -- the same loads, weights and operand order as the
-// setup kernel, so the values are bit-identical to the stored ones. Points that are out of the reference view at this
-// level keep using their stored (stale) patches (odometer.cpp:304). The stored patches stay the product's state
-// (pat_ref_all semantics, read-back, next frame); this only changes where an iteration reads them from.
-template <bool PN, int kU, bool NT = true, bool WH = false, bool RG = false>  // WH: also accumulate the 21 H sums
+// LD selects how stage 2 addresses memory (same bytes, same values):
+//   0  global loads (scalar base + per-lane 64-bit address arithmetic), window rows de-duplicated: own row pair per
+//      lane, the row above for lanes 0-7 only, everyone else by ds_bpermute from the lane one row up (round 1);
+//   1  the same loads as buffer loads: plane / patch-buffer descriptor in SGPRs, wave-uniform offset in an SGPR,
+//      per-lane constant byte offset in a VGPR -> no vector address arithmetic per load;
+//   2  buffer loads, and every lane loads its own two row pairs (x-1,x at y and y-1): no cross-lane traffic, no
+//      selects; neighbouring lanes' requests hit the same cache lines.
+// A wave issues at most one instruction of any kind per ~4 cycles, so at the coarse levels (frames cached) the
+// kernel's pace is its instruction count per patch, not bytes (profiles/r02_notes.md).
+template <bool PN, int kU, bool NT = true, bool WH = false, int LD = 0>  // WH: also accumulate the 21 H sums
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
-  constexpr int kRec = RG ? 24 : 16;  // RG: + [w0r w1r w2r w3r][base_r vis_r - -] of the reference-pose window
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartBStride];
   __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
@@ -510,9 +510,12 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   const float *__restrict__ Gy = e.Gy + (size_t)b * M * 64;
   const float *__restrict__ coefb = e.coef + (size_t)b * M * kCoefStride;
   gconst_f32 cur = (gconst_f32)pl.cur;
-  gconst_f32x4 ppack = (gconst_f32x4)pl.pack;
-  const float *__restrict__ pt2d = e.pt2d + ((size_t)b * e.nlev + level) * 2 * M;
   const int sw = lc.sw;
+  // LD >= 1: buffer descriptors (base, no stride, max range, raw dword format) of the current frame and the patches
+  const __amdgpu_buffer_rsrc_t rcur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl.cur), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rGx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Gx), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rGy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Gy), 0, 0x7fffffff, 0x00020000);
 
   float G[12];
 #pragma unroll
@@ -549,21 +552,13 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
     const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
     const int base_v = tp.row0 * sw + tp.col0;
-    int baser_v = 0, visr_v = 0;
     {
       float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
       r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
-      r4[1] = make_float4(q0.x, q0.z, q0.w, q1.x);
-      r4[2] = make_float4(q1.y, q1.w, q2.x, q2.y);
+      // [cx0 cy1 | cx2 cx3][cy2 cy3 | cx4 cx5][cy4 cy5 | vis -]: operand pairs of the packed multiply-adds below
+      r4[1] = make_float4(q0.x, q1.w, q0.z, q0.w);
+      r4[2] = make_float4(q2.x, q2.y, q1.x, q1.y);
       r4[3] = make_float4(q2.z, q2.w, vis ? 1.0f : 0.0f, 0.0f);
-      if constexpr (RG) {  // the reference-pose window of the point at this level (odometer.cpp:268-286), as in k_ref8
-        const float mxr = pt2d[ip], myr = pt2d[ip + M];
-        const bool visr = pv && in_view(mxr, myr, lc.swo, lc.sho);
-        const Taps tr = make_taps(visr ? mxr : 1.0f, visr ? myr : 1.0f, 4);
-        baser_v = tr.row0 * sw + tr.col0;
-        visr_v = visr ? 1 : 0;
-        r4[4] = make_float4(tr.w0, tr.w1, tr.w2, tr.w3);
-      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -571,72 +566,71 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
 
     // ---- stage 2. The kU patches of a step are nsteps apart (neighbouring points share frame cache lines).
     const int nsteps = (cnt + kU - 1) / kU;
-    auto issue = [&](PatchLoads<kU, RG> &L, int sidx) {
+    auto issue = [&](PatchLoads<kU> &L, int sidx) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int jraw = sidx + u * nsteps;
         const int jj = min(jraw, cnt - 1);
         L.rec[u] = (jraw < cnt) ? jj : -1;
         const int base = rlane(base_v, jj);
-        const size_t po = (size_t)(i0 + jj) * 64;  // wave-uniform: scalar base + 32-bit lane offset
-        bool stored = true;
-        if constexpr (RG) {
-          L.visr[u] = rlane(visr_v, jj);
-          if (L.visr[u]) {  // wave-uniform
-            L.p4[u] = taps_issue4(ppack + rlane(baser_v, jj), loff, sw, lane);
-            stored = false;
+        if constexpr (LD == 0) {
+          const size_t po = (size_t)(i0 + jj) * 64;  // wave-uniform: scalar base + 32-bit lane offset
+          if constexpr (NT) {  // streamed once per launch: keep them from evicting the (re-used) frame lines
+            L.t[u] = __builtin_nontemporal_load(T + po + lane);
+            L.gx[u] = __builtin_nontemporal_load(Gx + po + lane);
+            L.gy[u] = __builtin_nontemporal_load(Gy + po + lane);
+          } else {
+            L.t[u] = (T + po)[lane];
+            L.gx[u] = (Gx + po)[lane];
+            L.gy[u] = (Gy + po)[lane];
           }
-        }
-        if (!stored) {
-          L.t[u] = L.gx[u] = L.gy[u] = 0.0f;
-        } else if constexpr (NT) {  // streamed once per launch: keep them from evicting the (re-used) frame lines
-          L.t[u] = __builtin_nontemporal_load(T + po + lane);
-          L.gx[u] = __builtin_nontemporal_load(Gx + po + lane);
-          L.gy[u] = __builtin_nontemporal_load(Gy + po + lane);
+          L.cur[u] = taps_issue(cur + base, loff, sw, lane);
         } else {
-          L.t[u] = (T + po)[lane];
-          L.gx[u] = (Gx + po)[lane];
-          L.gy[u] = (Gy + po)[lane];
+          constexpr int aux = NT ? 2 : 0;  // gfx950 cache policy bits of a buffer load: bit 1 = nt
+          const int po4 = (i0 + jj) * 256;  // bytes: one 8x8 float patch = 256 B
+          L.t[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, lane * 4, po4, aux));
+          L.gx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, lane * 4, po4, aux));
+          L.gy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, lane * 4, po4, aux));
+          const int so = (base - sw - 1) * 4;  // bytes: the window's top-left texel (tap d of pixel 0)
+          const int off_cd = ((lane >> 3) * sw + (lane & 7)) * 4, off_ab = off_cd + sw * 4;
+          L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_ab, so, 0));
+          f32x2_a4 q = {0.0f, 0.0f};
+          if (LD == 2 || lane < 8) q = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_cd, so, 0));
+          L.cur[u].top = q;
         }
-        L.cur[u] = taps_issue(cur + base, loff, sw, lane);
       }
     };
-    auto reduce = [&](const PatchLoads<kU, RG> &L) {
+    auto reduce = [&](const PatchLoads<kU> &L) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (L.rec[u] < 0) continue;  // wave-uniform
-        constexpr int R4 = kRec / 4;
-        const float4 w = rec4[L.rec[u] * R4 + 0], k0 = rec4[L.rec[u] * R4 + 1], k1 = rec4[L.rec[u] * R4 + 2],
-                     k2 = rec4[L.rec[u] * R4 + 3];
-        float inew = taps_blend(L.cur[u], w.x, w.y, w.z, w.w, lane);
+        const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
+                     k2 = rec4[L.rec[u] * 4 + 3];
+        float inew;
+        if constexpr (LD == 2)  // utilities.cpp:107 in the reference's operand order, never contracted (see taps_blend)
+          inew = w.x * L.cur[u].ab.y + w.y * L.cur[u].ab.x + w.z * L.cur[u].top.y + w.w * L.cur[u].top.x;
+        else
+          inew = taps_blend(L.cur[u], w.x, w.y, w.z, w.w, lane);
         if constexpr (PN) inew -= wave_sum(inew) / 64.0f;  // utilities.cpp:111-112
-        float tv = L.t[u], gx = L.gx[u], gy = L.gy[u];
-        if constexpr (RG) {
-          if (L.visr[u]) {  // utilities.cpp:115-189 again, from the cache-resident packed plane (bit-identical values)
-            const float4 wr = rec4[L.rec[u] * R4 + 4];
-            tv = taps_blend4(L.p4[u], 0, wr.x, wr.y, wr.z, wr.w, lane);
-            gx = taps_blend4(L.p4[u], 1, wr.x, wr.y, wr.z, wr.w, lane);
-            gy = taps_blend4(L.p4[u], 2, wr.x, wr.y, wr.z, wr.w, lane);
-            if constexpr (PN) tv -= wave_sum(tv) / 64.0f;  // utilities.cpp:187-188
-          }
-        }
+        const float tv = L.t[u], gx = L.gx[u], gy = L.gy[u];
         const float r = (tv - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 for points out of view
         {
 #pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only: FMA allowed from here on
-          acc[0] += (gx * k0.x) * r;              // sd1 = Gx cx0
-          acc[1] += (gy * k1.y) * r;              // sd2 = Gy cy1
-          acc[2] += (gx * k0.y + gy * k1.z) * r;  // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
-          acc[3] += (gx * k0.z + gy * k1.w) * r;
-          acc[4] += (gx * k0.w + gy * k2.x) * r;
-          acc[5] += (gx * k1.x + gy * k2.y) * r;
+          const float gr = gx * r, hr = gy * r;
+          acc[0] += gr * k0.x;                // sd1 = Gx cx0
+          acc[1] += hr * k0.y;                // sd2 = Gy cy1
+          acc[2] += gr * k0.z + hr * k1.x;    // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
+          acc[3] += gr * k0.w + hr * k1.y;
+          acc[4] += gr * k1.z + hr * k2.x;
+          acc[5] += gr * k1.w + hr * k2.y;
           if constexpr (WH) {  // H = sum sd_j sd_k over every stored patch, visible or stale (odometer.cpp:428-455)
             float sd[6];
             sd[0] = gx * k0.x;
-            sd[1] = gy * k1.y;
-            sd[2] = gx * k0.y + gy * k1.z;
-            sd[3] = gx * k0.z + gy * k1.w;
-            sd[4] = gx * k0.w + gy * k2.x;
-            sd[5] = gx * k1.x + gy * k2.y;
+            sd[1] = gy * k0.y;
+            sd[2] = gx * k0.z + gy * k1.x;
+            sd[3] = gx * k0.w + gy * k1.y;
+            sd[4] = gx * k1.z + gy * k2.x;
+            sd[5] = gx * k1.w + gy * k2.y;
             int jk = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -646,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
         }
       }
     };
-    PatchLoads<kU, RG> A, B;
+    PatchLoads<kU> A, B;
     issue(A, 0);
     for (int sidx = 0; sidx < nsteps; sidx += 2) {
       if (sidx + 1 < nsteps) issue(B, sidx + 1);
@@ -694,6 +688,9 @@ struct RefLoads {
   int vis[kU];
 };
 
+// (Buffer addressing as in k_iter8 was measured here too, r02: 414/395/340 us per level with the round-1 addressing,
+// 441/405/346 with buffer loads + row-up shuffles, 429/399/336 with per-lane texel loads: noise. This kernel waits on
+// memory, not on instruction issue; the round-1 form stays.)
 template <bool PN, int kU, bool NT = true, bool WH = true, bool PK = false>  // WH = false: H deferred; PK: packed planes
 __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw, int dbg) {
   // dbg (variant bits 9-11, ablation experiments only, results wrong on purpose): 1 no stores, 2 one plane's taps
@@ -1557,32 +1554,32 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
     const dim3 g8(gridx8, e.B);
     // patches per pipeline step: 4 measured best (profiles/r01_notes.md); variant bits 4-5 select others for A/B
     const int ku = (variant >> 4) & 3;
+    // stage-2 addressing (see k_iter8): buffer loads + per-lane taps (LD = 2) measured best (r02: levels 1 / 2 195 ->
+    // 183 / 182 -> 165 us per launch); variant bits 16-17 = 1 / 2 select LD = 0 / 1 for A/B
+    const int ldsel = (variant >> 16) & 3;
     if (first && defer_h(e, variant)) {
       if (e.dopatchnorm)
-        hipLaunchKernelGGL((k_iter8<true, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
+        hipLaunchKernelGGL((k_iter8<true, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
       else if (ku == 2)
-        hipLaunchKernelGGL((k_iter8<false, 2, true, true>), g8, blk, 0, s, e, lc, level, cpw);
+        hipLaunchKernelGGL((k_iter8<false, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      else if (ldsel == 1)
+        hipLaunchKernelGGL((k_iter8<false, 4, true, true, 0>), g8, blk, 0, s, e, lc, level, cpw);
       else
-        hipLaunchKernelGGL((k_iter8<false, 4, true, true>), g8, blk, 0, s, e, lc, level, cpw);
-    } else if (e.packed && level >= 1 && (variant & 32768)) {
-      // experiment (variant bit 15, off by default): at coarse levels re-gather T/Gx/Gy from the cache-resident packed
-      // reference plane (k_iter8<.., RG = true>). Measured r02: 331 / 279 us per launch at levels 1 / 2 against
-      // 195 / 182 for the stored patches -- three more blends, 8 ds_bpermute and 167 VGPRs per patch cost more than
-      // the 0.8 GB of HBM reads they save (profiles/r02_notes.md)
-      if (e.dopatchnorm)
-        hipLaunchKernelGGL((k_iter8<true, 2, true, false, true>), g8, blk, 0, s, e, lc, level, cpw);
-      else
-        hipLaunchKernelGGL((k_iter8<false, 2, true, false, true>), g8, blk, 0, s, e, lc, level, cpw);
+        hipLaunchKernelGGL((k_iter8<false, 4, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
     } else if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_iter8<true, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<true, 2, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
-      hipLaunchKernelGGL((k_iter8<false, 1>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<false, 1, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 2)
-      hipLaunchKernelGGL((k_iter8<false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<false, 2, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 3)
-      hipLaunchKernelGGL((k_iter8<false, 4, false>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal loads
+      hipLaunchKernelGGL((k_iter8<false, 4, false, false, 2>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal loads
+    else if (ldsel == 1)
+      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 0>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (ldsel == 2)
+      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 1>), g8, blk, 0, s, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL((k_iter8<false, 4>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (fast4(e, variant)) {
     const dim3 g8(gridx8, e.B);
     if (first) {
