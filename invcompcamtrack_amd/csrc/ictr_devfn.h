@@ -277,7 +277,21 @@ __device__ __forceinline__ float ws_apply(const WaveSolver &s, float bi, int lan
   return lane_gather(c, s.colmap);
 }
 
-__device__ __forceinline__ void ws_level_reset(WaveSolver &s, const EngineDev &e) {  // odometer.cpp:341-346
+// what the solver needs of the engine's parameters (passed by value: 8 dwords instead of the whole EngineDev)
+struct SolveOpts {
+  int maxiter, robust;
+  float ratio;
+  DevTrace trace;
+};
+__device__ __forceinline__ SolveOpts solve_opts(const EngineDev &e) {
+  SolveOpts o;
+  o.maxiter = e.maxiter;
+  o.robust = e.robust;
+  o.ratio = e.ratio;
+  o.trace = e.trace;
+  return o;
+}
+__device__ __forceinline__ void ws_level_reset(WaveSolver &s, const SolveOpts &e) {  // odometer.cpp:341-346
   s.normdp_init = 1e-10f;
   s.normdp = 1e-10f;
   s.it = 0;
@@ -286,7 +300,7 @@ __device__ __forceinline__ void ws_level_reset(WaveSolver &s, const EngineDev &e
 
 // Steps 9b + 10 + loop condition (solve_and_update, wave form). bi: lane i < 6 holds sumsd[i]. G (uniform, 12
 // registers): cpos_G, current on entry, updated on return. The arithmetic is solve_and_update's.
-__device__ __forceinline__ void ws_iterate(WaveSolver &s, float bi, const EngineDev &e, int level, int prob, int lane,
+__device__ __forceinline__ void ws_iterate(WaveSolver &s, float bi, const SolveOpts &e, int level, int prob, int lane,
                                            float *G) {
 #ifdef ICTR_T1_PROF
   unsigned long long c0_ = __builtin_readcyclecounter(), c1_;

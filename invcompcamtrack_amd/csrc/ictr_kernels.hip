@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, in
   } else {
     ws_load_factor(S, st, lane);
   }
-  ws_iterate(S, (float)bs, e, level, b, lane, G);
+  ws_iterate(S, (float)bs, solve_opts(e), level, b, lane, G);
   ws_store_state(S, st, lane, G);
 }
 
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) void k_iter_finish(EngineDev e, int level, int 
   } else {
     ws_load_factor(S, st, lane);
   }
-  ws_iterate(S, bi, e, level, b, lane, G);
+  ws_iterate(S, bi, solve_opts(e), level, b, lane, G);
   ws_store_state(S, st, lane, G);
 }
 

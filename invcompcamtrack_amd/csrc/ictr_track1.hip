@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
       const int lo = r < c ? r : c, hi = r < c ? c : r;
       const int j = lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
       ws_factor(S, lane_gather((float)hs, j), lane);
-      ws_level_reset(S, e);
+      ws_level_reset(S, solve_opts(e));
       if (lane == 0) sActive = S.active;
     }
     __syncthreads();
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
         double bs = 0.0;
         if (lane < 6)
           for (int w = 0; w < nwaves; ++w) bs += (double)sPart[w][lane];
-        ws_iterate(S, (float)bs, e, sl, b, lane, G);
+        ws_iterate(S, (float)bs, solve_opts(e), sl, b, lane, G);
         if (lane == 0) {
 #pragma unroll
           for (int k = 0; k < 12; ++k) sG[k] = G[k];
@@ -611,6 +611,8 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
 
   ProbState &gst = e.st[b];
   const int npts = gst.npts;
+  SolveOpts sopt = solve_opts(e);
+  sopt.robust = 0;  // the host routes every behaviour-changing option to the any-size form: no compose / log code here
   WaveSolver S;  // wave 0 is the solver (ictr_devfn.h)
   float G[12];
   S.p = lane < 6 ? gst.p[lane] : 0.0f;
@@ -648,7 +650,8 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
     const PlaneSet pl = e.planes[b * e.nlev + sl];
     const unsigned off_cd = (unsigned)((lane >> 3) * sw + (lane & 7)) * 4u;  // bytes from the window's top-left texel
     const unsigned off_ab = off_cd + (unsigned)sw * 4u;
-    constexpr int kU = 2;
+    constexpr int kU = 2;   // patches per pipeline step of the level setup
+    constexpr int kUi = 2;  // ... of the iterations (4: 256 VGPRs + spills, no gain; measured r02)
     // ---------------------------------------------------------------- level setup (odometer.cpp:268-334, 428-472)
     {
       float acc[kHUnique];
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
       const int lo = r < c ? r : c, hi = r < c ? c : r;
       const int j = lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
       ws_factor(S, lane_gather((float)hs, j), lane);
-      ws_level_reset(S, e);
+      ws_level_reset(S, sopt);
       if (lane == 0) sActive = S.active;
     }
     __syncthreads();
@@ -813,9 +816,9 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T1_MARK(3)  // stage 1
         // stage 2: one patch per step, software-pipelined
-        auto issue = [&](T8Loads<kU> &L, int k) {
+        auto issue = [&](T8Loads<kUi> &L, int k) {
 #pragma unroll
-          for (int u = 0; u < kU; ++u) {
+          for (int u = 0; u < kUi; ++u) {
             const bool ok = k + u < cn;
             const int kk = ok ? k + u : k;
             L.k[u] = ok ? kk : -1;
@@ -851,11 +854,11 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
             }
           }
         };
-        auto reduce = [&](const T8Loads<kU> &L) {
-          float4 wv[kU], q0[kU], q1[kU], q2[kU];
-          float vf[kU];
+        auto reduce = [&](const T8Loads<kUi> &L) {
+          float4 wv[kUi], q0[kUi], q1[kUi], q2[kUi];
+          float vf[kUi];
 #pragma unroll
-          for (int u = 0; u < kU; ++u) {  // the patches' scalars: broadcast LDS reads, all in flight together
+          for (int u = 0; u < kUi; ++u) {  // the patches' scalars: broadcast LDS reads, all in flight together
             const int kk = L.k[u] < 0 ? 0 : L.k[u];
             const int i = wave + (c0 + kk) * nwaves;
 #ifdef ICTR_T1_PROF
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
             q2[u] = lCoef[i * 3 + 2];
           }
 #pragma unroll
-          for (int u = 0; u < kU; ++u) {
+          for (int u = 0; u < kUi; ++u) {
             if (L.k[u] < 0) continue;  // wave-uniform
             // utilities.cpp:107 in the reference's operand order, not contracted: ((w0 a + w1 b) + w2 c) + w3 d
             float inew = wv[u].y * L.cur[u].ab.y + wv[u].x * L.cur[u].ab.x + wv[u].w * L.cur[u].cd.y + wv[u].z * L.cur[u].cd.x;
@@ -891,13 +894,13 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
             }
           }
         };
-        T8Loads<kU> A, B;
+        T8Loads<kUi> A, B;
         issue(A, 0);
-        for (int k = 0; k < cn; k += 2 * kU) {
-          if (k + kU < cn) issue(B, k + kU);
+        for (int k = 0; k < cn; k += 2 * kUi) {
+          if (k + kUi < cn) issue(B, k + kUi);
           reduce(A);
-          if (k + 2 * kU < cn) issue(A, k + 2 * kU);
-          if (k + kU < cn) reduce(B);
+          if (k + 2 * kUi < cn) issue(A, k + 2 * kUi);
+          if (k + kUi < cn) reduce(B);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the records are rewritten by the next chunk
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
         double bs = 0.0;
         if (lane < 6)
           for (int w = 0; w < nwaves; ++w) bs += (double)sPart[w][lane];
-        ws_iterate(S, (float)bs, e, sl, b, lane, G);
+        ws_iterate(S, (float)bs, sopt, sl, b, lane, G);
         if (lane == 0) {
 #pragma unroll
           for (int k = 0; k < 12; ++k) sG[k] = G[k];
