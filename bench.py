@@ -70,8 +70,10 @@ def parse():
                     help="one engine, host and GPU strictly alternate (the pre-pipelining behaviour)")
     ap.add_argument("--groups", type=int, default=0,
                     help="sharded mode: force this many groups of pairs per rank (0 = choose by timing)")
-    ap.add_argument("--tune-groups", action="store_true",
-                    help="sharded mode: also time the two-group candidates (their launches overlap on two streams)")
+    ap.add_argument("--no-tune-groups", dest="tune_groups", action="store_false",
+                    help="sharded mode: do not time the two-group candidates (two groups of B/2 pairs per rank whose "
+                         "collectives hide behind each other's compute); by default every candidate is timed for two "
+                         "steps before the warm-up and the fastest is used")
     ap.add_argument("--rccl-direct", action="store_true",
                     help="sharded mode: also try the library's own in-stream RCCL communicator (dist.RcclDirect)")
     ap.add_argument("--p2p", action="store_true",
