@@ -321,6 +321,17 @@ class P2PDirect:
             pass
 
 
+class _OnStream:
+    """A torch.distributed work handle whose wait() holds up the given stream instead of the current one."""
+
+    def __init__(self, torch, stream, work):
+        self._torch, self._stream, self._work = torch, stream, work
+
+    def wait(self):
+        with self._torch.cuda.stream(self._stream):
+            self._work.wait()
+
+
 class ShardedTracker:
     """Drives one TrackBatch, or several (groups of problems that are software-pipelined against each other's
     collectives), in sharded mode. Collective path: RcclDirect (in-stream, when asked for and every rank can set it up),
@@ -341,9 +352,11 @@ class ShardedTracker:
             direct = os.environ.get("ICTR_RCCL_DIRECT") == "1"
         want_direct = (bool(direct) and not staged and dist.get_backend(group) == "nccl"
                        and not os.environ.get("ICTR_NO_RCCL_DIRECT"))
-        # direct path with several groups: every group gets its own stream AND its own communicator, so that one
-        # group's in-stream all-reduce (pure link latency) runs while the other group's kernels use the GPU
-        self._torch_streams = [torch.cuda.Stream() if (want_direct and len(self.batches) > 1) else None
+        # several groups: every group gets its own HIP stream, so that one group's collective (pure link latency), its
+        # latency-bound setup kernel and its launch gaps overlap the other group's HBM-bound iteration kernel -- the
+        # same effect as the two concurrent engines of the single-GPU mode (+8 %). The in-stream paths (P2P, direct
+        # RCCL) additionally get their own mailbox / communicator per group.
+        self._torch_streams = [torch.cuda.Stream() if (len(self.batches) > 1 and not staged) else None
                                for _ in self.batches]
         self._streams = []
         for b, ts in zip(self.batches, self._torch_streams):
@@ -380,9 +393,6 @@ class ShardedTracker:
                       "); using torch.distributed", file=sys.stderr)
                 for c in comms:
                     c.close()
-                for b in self.batches:
-                    b.set_stream(torch.cuda.current_stream().cuda_stream)
-                self._streams = [torch.cuda.current_stream().cuda_stream for _ in self.batches]
 
     def close(self):
         """Destroy the direct communicators (if any); the tracker falls back to torch.distributed afterwards."""
@@ -416,7 +426,14 @@ class ShardedTracker:
             dist.all_reduce(self._hosts[g], op=dist.ReduceOp.SUM, group=self.group)
             self.reds[g].copy_(self._hosts[g])
             return _Done()
-        return dist.all_reduce(self.reds[g], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        ts = self._torch_streams[g]
+        if ts is None:
+            return dist.all_reduce(self.reds[g], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # torch.distributed orders a collective after the CURRENT torch stream and wait() makes the CURRENT stream wait
+        # for it: issue and wait under the group's own stream, so that only this group's kernels are held up
+        with self._torch.cuda.stream(ts):
+            work = dist.all_reduce(self.reds[g], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return _OnStream(self._torch, ts, work)
 
     def _allreduce(self):  # the synchronous single-group form (kept for callers of run_sharded_levels)
         self._allreduce_async(0).wait()
