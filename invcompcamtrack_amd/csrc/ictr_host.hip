@@ -704,7 +704,12 @@ struct ictr_batch {
   int evk_iters = 0;
   int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
   int maxpts = 0;    // largest nopoints over the problems of the current tracking (set by ictr_batch_begin)
-  int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip)
+  int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip), 2: launches replayed as a graph
+  // the per-iteration launch sequence of one tracking as an instantiated hipGraph (launch-bound sizes, enqueue_levels)
+  hipGraphExec_t gexec = nullptr;
+  std::string gkey;               // everything the captured launches depend on; a change rebuilds the graph
+  hipStream_t cap_stream = nullptr;  // capture needs a non-null stream; nothing ever executes on it
+  bool graph_broken = false;      // capture / instantiate failed once: plain launches from then on
   int phase_it = 0;  // iteration counter of the phase API (event slot of the next iter_accumulate)
   float *d_red_own = nullptr;
   // results of the last track_async: the final states are copied to pinned host memory in-stream and an event marks
@@ -720,6 +725,8 @@ static void batch_free(ictr_batch *b) {
   if (!b) return;
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->evk) (void)hipEventDestroy(e);
+  if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+  if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
   if (b->done_ev) (void)hipEventDestroy(b->done_ev);
   if (b->up_ev) (void)hipEventDestroy(b->up_ev);
   if (b->h_st_pin) (void)hipHostFree(b->h_st_pin);
@@ -740,6 +747,7 @@ static int engine_variant(const ictr_batch *b) {
   }();
   return b->variant | env_or | (b->robust ? 2 : 0);
 }
+
 static EngineDev engine_dev(const ictr_batch *b) {
   EngineDev e;
   e.B = b->B;
@@ -1121,8 +1129,90 @@ static int track1_waves(const ictr_batch *b) {
   return forced > 0 ? forced : 8;
 }
 
+// Launch-bound sizes (a few hundred to a few thousand points: every kernel of the per-iteration form runs 2-5 us)
+// replay the whole launch sequence of a tracking -- (setup + tail) per level, (accumulate + tail) per iteration, 111
+// kernels for 5 levels x 10 iterations -- as ONE instantiated hipGraph: the host pays one graph launch instead of 111
+// kernel launches and the GPU finds the next packet already queued. The graph is captured once per batch and reused for
+// as long as nothing the launches depend on changes (kernel arguments are passed by value: pointers, sizes, options,
+// camera, grid shapes -- all of it goes into the key). Variant bit 15 (32768) keeps the plain launches (A/B).
+static bool use_graph(const ictr_batch *b) {
+  if (b->sharded || b->timing || b->graph_broken || (engine_variant(b) & 32768)) return false;
+  static const int64_t limit = [] {
+    const char *s = getenv("ICTR_GRAPH_MAXPTS");  // total points of a batch up to which the graph is used; 0 = never
+    return s ? (int64_t)atoll(s) : (int64_t)65536;
+  }();
+  return (int64_t)b->maxpts * b->B <= limit;
+}
+template <class T>
+static void key_put(std::string &k, const T &v) { k.append(reinterpret_cast<const char *>(&v), sizeof(T)); }
+static std::string graph_key(const ictr_batch *b, const EngineDev &e) {
+  std::string k;
+  for (int v : {e.B, e.M, e.P, e.n, e.nlev, e.lv_f, e.lv_l, e.maxiter, e.dopatchnorm, e.sharded, e.packed, e.robust,
+                e.trace.capacity, engine_variant(b), b->cpw, b->gridx, b->gridx8})
+    key_put(k, v);
+  key_put(k, e.ratio);
+  key_put(k, e.huber_k);
+  for (const void *q : {(const void *)e.pt3d, (const void *)e.pt3d_ref, (const void *)e.pt2d, (const void *)e.T,
+                        (const void *)e.Gx, (const void *)e.Gy, (const void *)e.coef, (const void *)e.st,
+                        (const void *)e.planes, (const void *)e.partH, (const void *)e.partb, (const void *)e.red,
+                        (const void *)e.trace.rec, (const void *)e.trace.count})
+    key_put(k, q);
+  for (int l = 0; l < b->nlev; ++l) {
+    const LevelCam lc = level_cam(b->cam, l);
+    for (float v : {lc.fx, lc.fy, lc.cx, lc.cy, lc.swo, lc.sho}) key_put(k, v);
+    key_put(k, lc.sw);
+  }
+  return k;
+}
+
 // split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket
 // the accumulate kernel alone
+static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t s, bool events) {
+  const int mi = b->op->maxiter;
+  const bool tk = events && (int)b->evk.size() >= 2 * b->nlev * mi && mi <= b->evk_iters;
+  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
+    const LevelCam lc = level_cam(b->cam, sl);
+    if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
+    launch_ref_level(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, s);
+    if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
+    for (int it = 0; it < mi; ++it) {
+      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it)], s));
+      launch_iter_main(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, it == 0, s);
+      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it) + 1], s));
+      launch_iter_tail(e, sl, b->gridx, engine_variant(b), b->gridx8, it == 0, s);
+    }
+    if (events) {
+      HIPCHK(hipEventRecord(b->ev[3 * sl + 2], s));
+      b->ev_used[sl] = 1;
+    }
+  }
+  return ICTR_OK;
+}
+
+// (re)build the graph of the current tracking's launches; false: fall back to plain launches for good
+static bool build_graph(ictr_batch *b, const EngineDev &e, const std::string &key) {
+  if (b->gexec) {
+    (void)hipGraphExecDestroy(b->gexec);
+    b->gexec = nullptr;
+  }
+  b->gkey.clear();
+  if (!b->cap_stream && hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) return false;
+  if (hipStreamBeginCapture(b->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+  const int rc = enqueue_level_kernels(b, e, b->cap_stream, false);
+  hipGraph_t g = nullptr;
+  const hipError_t ec = hipStreamEndCapture(b->cap_stream, &g);
+  bool ok = rc == ICTR_OK && ec == hipSuccess && g != nullptr;
+  if (ok) ok = hipGraphInstantiate(&b->gexec, g, nullptr, nullptr, 0) == hipSuccess;
+  if (g) (void)hipGraphDestroy(g);
+  if (!ok) {
+    (void)hipGetLastError();  // clear the sticky error of the failed capture
+    b->gexec = nullptr;
+    return false;
+  }
+  b->gkey = key;
+  return true;
+}
+
 static int enqueue_levels(ictr_batch *b) {
   const EngineDev e = engine_dev(b);
   b->last_path = 0;
@@ -1133,25 +1223,17 @@ static int enqueue_levels(ictr_batch *b) {
     b->last_path = 1;
     return ICTR_OK;
   }
-  if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
-  const int mi = b->op->maxiter;
-  const bool tk = b->timing && (int)b->evk.size() >= 2 * b->nlev * mi && mi <= b->evk_iters;
-  for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
-    const LevelCam lc = level_cam(b->cam, sl);
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], b->stream));
-    launch_ref_level(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, b->stream);
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], b->stream));
-    for (int it = 0; it < mi; ++it) {
-      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it)], b->stream));
-      launch_iter_main(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, it == 0, b->stream);
-      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it) + 1], b->stream));
-      launch_iter_tail(e, sl, b->gridx, engine_variant(b), b->gridx8, it == 0, b->stream);
+  if (use_graph(b)) {
+    const std::string key = graph_key(b, e);
+    if ((b->gexec && key == b->gkey) || build_graph(b, e, key)) {
+      HIPCHK(hipGraphLaunch(b->gexec, b->stream));
+      b->last_path = 2;
+      return ICTR_OK;
     }
-    if (b->timing) {
-      HIPCHK(hipEventRecord(b->ev[3 * sl + 2], b->stream));
-      b->ev_used[sl] = 1;
-    }
+    b->graph_broken = true;
   }
+  if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
+  if (int rc = enqueue_level_kernels(b, e, b->stream, b->timing)) return rc;
   HIPCHK(hipGetLastError());
   return ICTR_OK;
 }

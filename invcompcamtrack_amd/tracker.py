@@ -443,8 +443,10 @@ class TrackBatch:
         return a, b
 
     def path_name(self):
-        """Launch form of the last tracking: per-iteration launches or the one-launch small-problem tracker."""
-        return {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)"}.get(
+        """Launch form of the last tracking: per-iteration launches (plain, or replayed as one hipGraph) or the
+        one-launch small-problem tracker."""
+        return {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)",
+                2: "k_iter* (per-iteration launches replayed as one hipGraph)"}.get(
             _lib.load().ictr_batch_last_path(self._h), "?")
 
     def set_reduction_buffer(self, dev_ptr):

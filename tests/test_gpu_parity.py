@@ -35,6 +35,7 @@ DP_TOL = 2e-3
 
 LAUNCHES = 8192   # variant bit 13: per-iteration launch pairs (k_ref* / k_iter* + tails) whatever the problem size
 ONE_LAUNCH = 16384  # variant bit 14: the one-launch tracker k_track1 (default choice for small problems)
+NO_GRAPH = 32768  # variant bit 15: the per-iteration launches as plain launches (default below 65 536 points: one hipGraph)
 
 
 @pytest.fixture(params=["one_launch", "launches"])
@@ -255,6 +256,48 @@ def test_one_launch_tracker_equals_per_iteration_launches(oracle, cfg):
     assert np.array_equal(one[2], many[2]), "sd coefficients differ between the launch forms"
     assert [(r["level"], r["iter"]) for r in one[3]] == [(r["level"], r["iter"]) for r in many[3]]
     assert rel(one[3][0]["H"], many[3][0]["H"]) <= SUM_TOL and rel(one[3][0]["b"], many[3][0]["b"]) <= SUM_TOL
+
+
+def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
+    """Launch-bound sizes replay the per-iteration launch sequence as one instantiated hipGraph (enqueue_levels): the
+    SAME kernels with the SAME arguments, so every bit must agree with the plain launches -- also on the second
+    tracking (graph reused), after new points / a new frame pair (data behind the same pointers), and after option
+    changes that alter the captured launches (maxiter, dopatchnorm, normdp_ratio: the graph must be rebuilt)."""
+    sc = scene(320, 240, 700, seed=77)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    ops = [ic.optparam(2, 0, 8, 6, 0.0, 0, 0, 700) for _ in range(2)]
+    eng = []
+    for op, variant in zip(ops, (LAUNCHES, LAUNCHES | NO_GRAPH)):
+        e = ic.TrackBatch(cam, op, 2)
+        e.set_variant(variant)
+        eng.append(e)
+
+    def both(npts, pose_shift, swap=False):
+        res = []
+        for e in eng:
+            for k in range(2):
+                e.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :npts - 50 * k].copy()))
+                e.SetPose(k, sc["p_a"] + pose_shift * (k + 1), pb if swap else pa, pa if swap else pb)
+            e.track_async()
+            res.append((e.poses().copy(), e.iterations().copy(), e.path_name()))
+        assert "hipGraph" in res[0][2] and "hipGraph" not in res[1][2], (res[0][2], res[1][2])
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        return res[0]
+
+    first = both(700, 0.0)
+    again = both(700, 0.0)
+    assert np.array_equal(first[0], again[0])
+    both(400, 1e-3, swap=True)
+    for field, value in (("maxiter", 3), ("dopatchnorm", 1), ("normdp_ratio", 0.05), ("maxiter", 6)):
+        for op in ops:
+            setattr(op, field, value)
+        r = both(700, 0.0)
+        if field == "maxiter":
+            assert int(r[1].max()) <= 3 * value
+    for op in ops:
+        op.dopatchnorm, op.normdp_ratio = 0, 0.0
+    assert np.array_equal(both(700, 0.0)[0], first[0])
 
 
 def test_one_launch_tracker_is_the_default_for_small_batches(oracle):
