@@ -29,6 +29,8 @@ class Pyramid {
     check(ictr_pyramid_create(&h_, img, w, h, lv_f, getgrad ? 1 : 0, imgpadding), "util_constructpyramide");
   }
   ~Pyramid() { ictr_pyramid_destroy(h_); }
+  // the next frame of a sequence into the same planes (no allocation)
+  void rebuild(const float *img) { check(ictr_pyramid_rebuild(h_, img, nullptr), "util_constructpyramide (rebuild)"); }
   Pyramid(const Pyramid &) = delete;
   Pyramid &operator=(const Pyramid &) = delete;
   const ictr_pyramid *handle() const { return h_; }

@@ -99,6 +99,11 @@ int ictr_pyramid_create(ictr_pyramid **out, const float *img, int w, int h, int 
 /* same, img already in device memory (stays caller-owned; only read during the call) */
 int ictr_pyramid_create_device(ictr_pyramid **out, const float *img_dev, int w, int h, int lv_f, int getgrad,
                                int pad, void *hip_stream);
+/* Refill an existing pyramid from a new frame of the same size (the per-frame util_constructpyramide of a video loop,
+ * run_track_nposes.cpp:180 once per image of a sequence): no allocation, the planes keep their addresses. img_dev: device memory, read by kernels
+ * enqueued on hip_stream; img: host memory, copied to a device staging buffer first (has left `img` on return). */
+int ictr_pyramid_rebuild_device(ictr_pyramid *pyr, const float *img_dev, void *hip_stream);
+int ictr_pyramid_rebuild(ictr_pyramid *pyr, const float *img, void *hip_stream);
 /* adopts caller-built host planes (the reference's img_pyr / dx_pyr / dy_pyr arrays); dx/dy may be NULL */
 int ictr_pyramid_create_from_host_planes(ictr_pyramid **out, const float **img_pyr, const float **dx_pyr,
                                          const float **dy_pyr, int w, int h, int lv_f, int pad);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "ictr_solve6": (None, [FP, FP, FP]),
     "ictr_pyramid_create": (C.c_int, [C.POINTER(VP), FP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ictr_pyramid_create_device": (C.c_int, [C.POINTER(VP), VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "ictr_pyramid_rebuild_device": (C.c_int, [VP, VP, VP]),
+    "ictr_pyramid_rebuild": (C.c_int, [VP, FP, VP]),
     "ictr_pyramid_create_from_host_planes": (C.c_int, [C.POINTER(VP), FPP, FPP, FPP, C.c_int, C.c_int, C.c_int,
                                                        C.c_int]),
     "ictr_pyramid_destroy": (None, [VP]),

@@ -20,6 +20,8 @@ void launch_pyr_copy(const float *, float *, int, int, int, int, hipStream_t);
 void launch_pyr_down(const float *, int, int, int, float *, int, int, int, int, hipStream_t);
 void launch_pyr_finish(float *, float *, float *, int, int, int, int, int, int, hipStream_t);
 void launch_pyr_pack(const float *, const float *, const float *, float *, size_t, hipStream_t);
+void launch_pyr_level(const float *, int, int, int, int, float *, float *, float *, float *, int, int, int, int, int, int,
+                      hipStream_t);
 void launch_stream_read(const float *, size_t, float *, hipStream_t);
 void launch_getpatch(const float *, const float *, const float *, const float *, int, int, int, int, float *, float *,
                      float *, hipStream_t);
@@ -262,6 +264,7 @@ struct ictr_pyramid {
   std::vector<float *> img, dx, dy;  // device planes
   std::vector<float *> pack;         // with gradients: the level again as interleaved {img, dx, dy, 0} texels
   float *arena = nullptr;
+  float *stage = nullptr;  // device copy of a host frame handed to ictr_pyramid_rebuild (allocated on first use)
 };
 
 struct ictr_pyramid_view {  // internal: what ictr_icgn.hip needs to know about a pyramid
@@ -343,7 +346,22 @@ static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad
 }
 
 static int pyramid_build(ictr_pyramid *p, const float *img_dev, hipStream_t s) {
+  // one launch per level (k_pyr_level); ICTR_PYR_UNFUSED=1: the four-kernel form it replaced (bit-identical planes,
+  // kept for the A/B and as a cross-check in the tests)
+  static const bool unfused = [] {
+    const char *v = getenv("ICTR_PYR_UNFUSED");
+    return v && atoi(v) != 0;
+  }();
   for (int l = 0; l < p->nlev; ++l) {
+    if (!unfused) {
+      if (l == 0)
+        launch_pyr_level(img_dev, 1, p->w[0], p->h[0], p->w[0], p->img[0], p->dx[0], p->dy[0], p->pack[0], p->w[0],
+                         p->h[0], p->pad, p->sw[0], p->sh[0], p->getgrad, s);
+      else
+        launch_pyr_level(p->img[l - 1], 0, p->w[l - 1], p->h[l - 1], p->sw[l - 1], p->img[l], p->dx[l], p->dy[l],
+                         p->pack[l], p->w[l], p->h[l], p->pad, p->sw[l], p->sh[l], p->getgrad, s);
+      continue;
+    }
     if (l == 0)
       launch_pyr_copy(img_dev, p->img[0], p->w[0], p->h[0], p->pad, p->sw[0], s);
     else
@@ -354,6 +372,21 @@ static int pyramid_build(ictr_pyramid *p, const float *img_dev, hipStream_t s) {
   }
   HIPCHK(hipGetLastError());
   return ICTR_OK;
+}
+
+// A video loop builds one pyramid per incoming frame (run_track_nposes.cpp:180: one per image of the sequence): refill an
+// existing pyramid in place -- no allocation, every plane keeps its address (batches / graphs that hold them stay valid).
+extern "C" int ictr_pyramid_rebuild_device(ictr_pyramid *p, const float *img_dev, void *hip_stream) {
+  if (!p || !img_dev) return fail(ICTR_ERR_INVALID, "pyramid_rebuild: NULL argument");
+  return pyramid_build(p, img_dev, (hipStream_t)hip_stream);
+}
+extern "C" int ictr_pyramid_rebuild(ictr_pyramid *p, const float *img, void *hip_stream) {
+  if (!p || !img) return fail(ICTR_ERR_INVALID, "pyramid_rebuild: NULL argument");
+  const size_t bytes = sizeof(float) * (size_t)p->w0 * p->h0;
+  if (!p->stage) HIPCHK(hipMalloc((void **)&p->stage, bytes));
+  // pageable host memory: the copy has left `img` when the call returns; the kernels are ordered behind it on the stream
+  HIPCHK(hipMemcpyAsync(p->stage, img, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+  return pyramid_build(p, p->stage, (hipStream_t)hip_stream);
 }
 
 extern "C" int ictr_pyramid_create_device(ictr_pyramid **out, const float *img_dev, int w, int h, int lv_f, int getgrad,
@@ -418,6 +451,7 @@ extern "C" int ictr_pyramid_create_from_host_planes(ictr_pyramid **out, const fl
 extern "C" void ictr_pyramid_destroy(ictr_pyramid *p) {
   if (!p) return;
   if (p->arena) hipFree(p->arena);
+  if (p->stage) hipFree(p->stage);
   delete p;
 }
 extern "C" int ictr_pyramid_levels(const ictr_pyramid *p) { return p ? p->nlev : 0; }

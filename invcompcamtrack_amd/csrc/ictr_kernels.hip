@@ -1415,6 +1415,57 @@ __global__ __launch_bounds__(kBlock) void k_pyr_finish(float *img, float *dx, fl
   }
 }
 
+// One launch per level (the builder's default): every thread owns one pixel of the PADDED level and evaluates the level
+// image where it needs it straight from the level above (level 0: from the input frame) -- its own value (clamped:
+// replicate padding), and for interior pixels the four reflect-101 neighbours of the Sobel pair -- with exactly the
+// arithmetic of k_pyr_copy / k_pyr_down / k_pyr_finish / k_pyr_pack, so the planes are bit-identical to the
+// four-kernel form; the redundant evaluations are cache hits, the level is written once (img, dx, dy, packed texel).
+template <bool FIRST>
+__device__ __forceinline__ float pyr_level_value(const float *__restrict__ src, int pw, int ph, int psw, int pad, int w,
+                                                 int h, int x, int y) {
+  if constexpr (FIRST) return src[(size_t)y * w + x];
+  const float *s = src + (size_t)pad * psw + pad;  // interior origin of the previous level
+  if (pw == 2 * w && ph == 2 * h) {
+    const float *r0 = s + (size_t)(2 * y) * psw + 2 * x;
+    const float *r1 = r0 + psw;
+    return ((r0[0] + r1[0]) + (r0[1] + r1[1])) * 0.25f;
+  }
+  int y0 = 2 * y, y1 = y0 + 1, x0 = 2 * x, x1 = x0 + 1;
+  y0 = min(y0, ph - 1);
+  y1 = min(y1, ph - 1);
+  x0 = min(x0, pw - 1);
+  x1 = min(x1, pw - 1);
+  const float top = s[(size_t)y0 * psw + x0] * 0.5f + s[(size_t)y0 * psw + x1] * 0.5f;
+  const float bot = s[(size_t)y1 * psw + x0] * 0.5f + s[(size_t)y1 * psw + x1] * 0.5f;
+  return top * 0.5f + bot * 0.5f;
+}
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_pyr_level(const float *__restrict__ src, int pw, int ph, int psw, float *img,
+                                                      float *dx, float *dy, f32x4_t *pack, int w, int h, int pad, int sw,
+                                                      int sh, int getgrad) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * kWaves + (threadIdx.x >> 6);
+  if (x >= sw || y >= sh) return;
+  const int ix = x - pad, iy = y - pad;
+  const bool inside = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h);
+  const int cxx = min(max(ix, 0), w - 1), cyy = min(max(iy, 0), h - 1);
+  const size_t o = (size_t)y * sw + x;
+  const float v = pyr_level_value<FIRST>(src, pw, ph, psw, pad, w, h, cxx, cyy);
+  img[o] = v;
+  if (!getgrad) return;
+  float gx = 0.0f, gy = 0.0f;
+  if (inside) {
+    gx = pyr_level_value<FIRST>(src, pw, ph, psw, pad, w, h, reflect101(ix + 1, w), iy) -
+         pyr_level_value<FIRST>(src, pw, ph, psw, pad, w, h, reflect101(ix - 1, w), iy);
+    gy = pyr_level_value<FIRST>(src, pw, ph, psw, pad, w, h, ix, reflect101(iy + 1, h)) -
+         pyr_level_value<FIRST>(src, pw, ph, psw, pad, w, h, ix, reflect101(iy - 1, h));
+  }
+  dx[o] = gx;
+  dy[o] = gy;
+  const f32x4_t t = {v, gx, gy, 0.0f};
+  pack[o] = t;
+}
+
 // ---------------------------------------------------------------- host-side launchers
 static inline dim3 grid2d(int w, int h) { return dim3((w + 63) / 64, (h + kWaves - 1) / kWaves); }
 
@@ -1460,6 +1511,16 @@ __global__ __launch_bounds__(kBlock) void k_pyr_pack(const float *__restrict__ i
 void launch_pyr_pack(const float *img, const float *dx, const float *dy, float *pack, size_t n, hipStream_t s) {
   const int g = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 8192);
   hipLaunchKernelGGL(k_pyr_pack, dim3(g), dim3(kBlock), 0, s, img, dx, dy, reinterpret_cast<f32x4_t *>(pack), n);
+}
+// src: the input frame (first, unpadded, stride w) or the previous level's padded image plane (pw x ph, stride psw)
+void launch_pyr_level(const float *src, int first, int pw, int ph, int psw, float *img, float *dx, float *dy,
+                      float *pack, int w, int h, int pad, int sw, int sh, int getgrad, hipStream_t s) {
+  if (first)
+    hipLaunchKernelGGL(k_pyr_level<true>, grid2d(sw, sh), dim3(kBlock), 0, s, src, pw, ph, psw, img, dx, dy,
+                       reinterpret_cast<f32x4_t *>(pack), w, h, pad, sw, sh, getgrad);
+  else
+    hipLaunchKernelGGL(k_pyr_level<false>, grid2d(sw, sh), dim3(kBlock), 0, s, src, pw, ph, psw, img, dx, dy,
+                       reinterpret_cast<f32x4_t *>(pack), w, h, pad, sw, sh, getgrad);
 }
 void launch_pyr_finish(float *img, float *dx, float *dy, int w, int h, int pad, int sw, int sh, int getgrad,
                        hipStream_t s) {

@@ -100,6 +100,19 @@ class Pyramid:
             _lib.load().ictr_pyramid_destroy(self._h)
             self._h = None
 
+    def rebuild(self, img=None, *, device_ptr=None, stream=None):
+        """Refill this pyramid from a new frame of the same size (no allocation, the planes keep their addresses):
+        ``img`` a host array, or ``device_ptr`` a frame already in device memory; enqueued on ``stream``."""
+        L = _lib.load()
+        if device_ptr is not None:
+            check(L.ictr_pyramid_rebuild_device(self._h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)))
+        else:
+            img = f32c(img)
+            if img.shape != (self.h, self.w):
+                raise ValueError(f"rebuild needs a {self.w}x{self.h} frame, got {img.shape[1]}x{img.shape[0]}")
+            check(L.ictr_pyramid_rebuild(self._h, fp(img), C.c_void_p(stream or 0)))
+        return self
+
     def level_dims(self, level):
         sw, sh = C.c_int(), C.c_int()
         check(_lib.load().ictr_pyramid_level_dims(self._h, level, C.byref(sw), C.byref(sh)))

@@ -36,6 +36,46 @@ def test_pyramid_from_device_pointer_and_host_planes(oracle):
         assert np.array_equal(h.download(l, 1), o.dx[l])
 
 
+def test_pyramid_rebuild_in_place_host_and_device(oracle):
+    """A video loop refills one pyramid per incoming frame (run_track_nposes.cpp:180 builds one per image): same planes
+    as a fresh build, bit for bit, also the packed texels the setup kernel reads (checked through a tracking)."""
+    import torch
+    from parity_util import scene
+    sc = scene(200, 120, 150, seed=3)
+    rng = np.random.default_rng(6)
+    other = rng.uniform(0, 255, (120, 200)).astype(np.float32)
+    g = ic.Pyramid(other, 2, 8)
+    planes0 = [g.device_plane(l, w) for l in range(3) for w in range(3)] if hasattr(g, "device_plane") else None
+    for source in ("host", "device"):
+        for img in (sc["img_a"], other, sc["img_a"]):
+            if source == "host":
+                g.rebuild(img)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(img, np.float32)).cuda()
+                g.rebuild(device_ptr=t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            o = oracle.Pyramid(img, 2, 8)
+            for l in range(3):
+                for w, ref in ((0, o.img), (1, o.dx), (2, o.dy)):
+                    assert np.array_equal(g.download(l, w), ref[l]), (source, l, w)
+    if planes0 is not None:
+        assert planes0 == [g.device_plane(l, w) for l in range(3) for w in range(3)]
+    with pytest.raises(ValueError):
+        g.rebuild(np.zeros((10, 10), np.float32))
+    # g now holds img_a: tracking against it == tracking against a freshly built pyramid
+    op = ic.optparam(2, 0, 8, 4, 0.0, 0, 0, 150)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pb = ic.Pyramid(sc["img_b"], 2, 8)
+    poses = []
+    for pa in (g, ic.Pyramid(sc["img_a"], 2, 8)):
+        e = ic.TrackBatch(cam, op, 1)
+        e.Set3Dpoints(0, sc["pts3d"].copy())
+        e.SetPose(0, sc["p_a"], pa, pb)
+        e.track_async()
+        poses.append(e.poses().copy())
+    assert np.array_equal(poses[0], poses[1])
+
+
 @pytest.mark.parametrize("psz,dpn", [(8, 0), (4, 0), (8, 1), (5, 0), (31, 0), (16, 1)])
 def test_get_patch_bit_exact_incl_borders(oracle, psz, dpn):
     rng = np.random.default_rng(psz)

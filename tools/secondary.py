@@ -6,6 +6,7 @@
   C4          BASELINE config 4: 4096 independent 31x31 patches on a 1080p pair, 3 levels (flow producer)
   nposes      run_track_nposes' shape (run_ransac_test.m:67,88): 500 pose samples x 60 points, 10 frame pairs
   small       one 100-point frame pair at the reference's own size (run_odometer_test.m), latency
+  pyramid     util_constructpyramide (utilities.cpp:14-52) of a 1080p frame, 3 levels, refilled in place per frame
 
 Every record carries its own algorithmic bytes, the measured kernel time (HIP events on the launching stream) and
 achieved / 8 TB/s. Extension engines (C3, C4, C5) are build-defined: "parity unpinned by the reference".
@@ -230,9 +231,41 @@ def rec_small(seconds):
             "algorithmic_bytes_per_launch": None, "frac": None, "note": "latency-bound"}
 
 
+def rec_pyramid(seconds):
+    import torch
+    import invcompcamtrack_amd as ic
+    w, h, lv_f, pad, K = 1920, 1080, 2, 8, 16
+    rng = np.random.default_rng(3)
+    frame = torch.from_numpy(rng.integers(0, 256, (h, w)).astype(np.float32)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    pyr = ic.Pyramid(lv_f=lv_f, imgpadding=pad, device_ptr=frame.data_ptr(), wh=(w, h), stream=st)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = []
+
+    def step():  # K frames back to back (torch's current stream is the stream the kernels are launched on)
+        ev0.record()
+        for _ in range(K):
+            pyr.rebuild(device_ptr=frame.data_ptr(), stream=st)
+        ev1.record()
+        ev1.synchronize()
+        times.append(ev0.elapsed_time(ev1) * 1e-3 / K)
+
+    _budget_loop(step, seconds)
+    t = float(np.median(times[1:] or times))
+    px_in = sum((w >> l) * (h >> l) for l in range(lv_f + 1))
+    px_out = sum(pyr.level_dims(l)[0] * pyr.level_dims(l)[1] for l in range(lv_f + 1))
+    alg = 4.0 * px_in + 28.0 * px_out  # read every level's source once; write image, dx, dy and the 16-B packed texel
+    return {"name": "pyramid", "workload": f"util_constructpyramide of one {w}x{h} frame (device-resident f32), {lv_f + 1} "
+            f"levels, padding {pad}, gradients + packed texels, refilled in place ({K} frames back to back per sample)",
+            "value": 1.0 / t, "unit": "frames/s", "ms_per_step": t * 1e3, "reps": len(times), "kernel": "k_pyr_level "
+            "(one launch per level)", "kernel_us": t * 1e6, "algorithmic_bytes_per_launch": alg,
+            "achieved_GBps": alg / t / 1e9, "frac": alg / t / 1e9 / PEAK,
+            "note": "three dependent launches per frame; bit-exact against the oracle (tests/test_gpu_pyramid_patch.py)"}
+
+
 def run_all(seconds=1.0):
     recs = []
-    for fn in (rec_psz4, rec_c3, rec_c5, rec_c4, rec_nposes, rec_small):
+    for fn in (rec_psz4, rec_c3, rec_c5, rec_c4, rec_nposes, rec_small, rec_pyramid):
         t0 = time.perf_counter()
         try:
             r = fn(seconds)
