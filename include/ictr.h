@@ -210,6 +210,9 @@ int ictr_batch_set3dpoints_norm(ictr_batch *b, int64_t problem, double *pt_in, i
 int ictr_batch_get_norm(const ictr_batch *b, int64_t problem, double *meanshift3, double *varval);
 int ictr_batch_setpose(ictr_batch *b, int64_t problem, const double *p_in, const ictr_pyramid *pyr_ref,
                        const ictr_pyramid *pyr_new);
+/* SetPose of every problem in one call: p_all[6*nproblems], all problems on the same frame pair (pose samples) */
+int ictr_batch_setpose_all(ictr_batch *b, const double *p_all, const ictr_pyramid *pyr_ref,
+                           const ictr_pyramid *pyr_new);
 /* enqueue SetPose's projection + the whole coarse-to-fine loop for every problem; asynchronous */
 int ictr_batch_track_async(ictr_batch *b);
 /* wait and fetch all poses: p_out[6*nproblems] */

@@ -109,6 +109,7 @@ SIGNATURES = {
     "ictr_batch_set3dpoints_norm": (C.c_int, [VP, I64, DP, I64, DP, C.c_double]),
     "ictr_batch_get_norm": (C.c_int, [VP, I64, DP, DP]),
     "ictr_batch_setpose": (C.c_int, [VP, I64, DP, VP, VP]),
+    "ictr_batch_setpose_all": (C.c_int, [VP, DP, VP, VP]),
     "ictr_batch_track_async": (C.c_int, [VP]),
     "ictr_batch_get_poses": (C.c_int, [VP, DP]),
     "ictr_batch_get_iterations": (C.c_int, [VP, IP]),

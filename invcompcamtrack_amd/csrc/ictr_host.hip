@@ -1002,6 +1002,16 @@ extern "C" int ictr_batch_setpose(ictr_batch *b, int64_t problem, const double *
   return ICTR_OK;
 }
 
+// SetPose for every problem of the batch in one call: p_all[6 * nproblems], one frame pair shared by all (the
+// run_track_nposes shape: every pose sample tracks the same pair, run_track_nposes.cpp:232-258)
+extern "C" int ictr_batch_setpose_all(ictr_batch *b, const double *p_all, const ictr_pyramid *pyr_ref,
+                                      const ictr_pyramid *pyr_new) {
+  if (!b || !p_all) return fail(ICTR_ERR_INVALID, "setpose_all: bad arguments");
+  for (int64_t k = 0; k < b->B; ++k)
+    if (int rc = ictr_batch_setpose(b, k, p_all + 6 * k, pyr_ref, pyr_new)) return rc;
+  return ICTR_OK;
+}
+
 // upload poses + plane tables, zero the tickets, run step 3 for every problem
 extern "C" int ictr_batch_begin(ictr_batch *b) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");

@@ -45,8 +45,7 @@ def _track_samples(cam, op, pyrs, sample_ids, inp, out_pose, pts2d):
 
     def reproject(poses):
         out = []
-        for k in range(B):
-            batch.SetPose(k, poses[k], pyrs[0], pyrs[0])  # images are dummies here (run_track_nposes.cpp:219,241,260)
+        batch.SetPoseAll(poses, pyrs[0], pyrs[0])  # images are dummies here (run_track_nposes.cpp:219,241,260)
         batch.begin()
         for k in range(B):
             p2 = batch.Get2DPoints(k)
@@ -61,8 +60,7 @@ def _track_samples(cam, op, pyrs, sample_ids, inp, out_pose, pts2d):
     cpos = start.copy()
     for fr in range(nfwd):
         fr_t = fr + nback
-        for k in range(B):
-            batch.SetPose(k, cpos[k], pyrs[fr_t], pyrs[fr_t + 1])
+        batch.SetPoseAll(cpos, pyrs[fr_t], pyrs[fr_t + 1])
         batch.track_async()
         cpos = batch.poses()
         for k, sid in enumerate(sample_ids):
@@ -72,8 +70,7 @@ def _track_samples(cam, op, pyrs, sample_ids, inp, out_pose, pts2d):
     cpos = start.copy()
     for fr in range(nback):
         fr_t = nback - fr
-        for k in range(B):
-            batch.SetPose(k, cpos[k], pyrs[fr_t], pyrs[fr_t - 1])
+        batch.SetPoseAll(cpos, pyrs[fr_t], pyrs[fr_t - 1])
         batch.track_async()
         cpos = batch.poses()
         for k, sid in enumerate(sample_ids):

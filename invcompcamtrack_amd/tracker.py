@@ -395,6 +395,16 @@ class TrackBatch:
         self._keep[problem] = (img_ref, img_new)
         check(_lib.load().ictr_batch_setpose(self._h, problem, dp(p_in), img_ref._h, img_new._h))
 
+    def SetPoseAll(self, poses, img_ref, img_new):
+        """SetPose for every problem in one call: ``poses`` (B, 6), all on the same frame pair (pose samples of
+        run_track_nposes.cpp:232-258) -- one library call instead of B."""
+        poses = f64c(poses)
+        if poses.shape != (self.B, 6):
+            raise ValueError(f"SetPoseAll needs a ({self.B}, 6) array of poses, got {poses.shape}")
+        for k in range(self.B):
+            self._keep[k] = (img_ref, img_new)
+        check(_lib.load().ictr_batch_setpose_all(self._h, dp(poses), img_ref._h, img_new._h))
+
     def track_async(self):
         check(_lib.load().ictr_batch_track_async(self._h))
 

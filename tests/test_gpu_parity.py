@@ -300,6 +300,30 @@ def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
     assert np.array_equal(both(700, 0.0)[0], first[0])
 
 
+def test_setpose_all_equals_one_setpose_per_problem(oracle):
+    """ictr_batch_setpose_all (one call for every pose sample of a frame pair) == the SetPose loop, bit for bit."""
+    sc = scene(320, 240, 60, seed=31)
+    op = ic.optparam(2, 0, 8, 5, 0.0, 0, 0, 60)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    poses = sc["p_a"][None, :] + np.random.default_rng(2).normal(0, 1e-3, (24, 6))
+    out = []
+    for mode in ("loop", "all"):
+        b = ic.TrackBatch(cam, op, 24)
+        for k in range(24):
+            b.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :30 + k].copy()))
+        if mode == "loop":
+            for k in range(24):
+                b.SetPose(k, poses[k], pa, pb)
+        else:
+            b.SetPoseAll(poses, pa, pb)
+        b.track_async()
+        out.append(b.poses().copy())
+    assert np.array_equal(out[0], out[1])
+    with pytest.raises(ValueError):
+        b.SetPoseAll(poses[:5], pa, pb)
+
+
 def test_one_launch_tracker_is_the_default_for_small_batches(oracle):
     """run_track_nposes' shape: many small independent problems = one workgroup each, one launch per frame pair;
     large problems keep the per-iteration launches."""

@@ -31,8 +31,10 @@ def one(w, h, n, psz, lv_f, maxiter, B=1, reps=40, cpu=True):
         ts = []
         for r in range(reps + 5):
             t0 = time.perf_counter()
-            for k in range(B):
-                eng.SetPose(k, sc["p_a"], pa, pb)
+            if B > 1:  # one call for all problems (the run_track_nposes driver does the same)
+                eng.SetPoseAll(np.tile(sc["p_a"], (B, 1)), pa, pb)
+            else:
+                eng.SetPose(0, sc["p_a"], pa, pb)
             eng.track_async()
             p = eng.poses()
             ts.append(time.perf_counter() - t0)

@@ -175,8 +175,7 @@ def rec_nposes(seconds):
         p = starts
         for k in range(links):
             ref, new = (pa, pb) if k % 2 == 0 else (pb, pa)
-            for j in range(S):
-                eng.SetPose(j, p[j], ref, new)
+            eng.SetPoseAll(p, ref, new)
             eng.track_async()
             p = eng.poses()
         return p
