@@ -71,51 +71,12 @@ static_assert(sizeof(T1Rec) == 64, "record must be one 64-byte row");
     if (lane < (N)) (dst)[lane] = o_;                  \
   }
 
-// ---- 8x8 patches, lane == pixel. Per-lane constants of a level (byte offsets from the window's top-left texel
-// (base - sw - 1)): the lane's own row pair (x-1,y),(x,y), and for the lanes of patch row 0 the pair one row up.
 typedef const char __attribute__((address_space(1))) *gconst_bytes;
-struct T1Lane {
-  unsigned off_ab, off_top;  // bytes
-  int up4;                   // ds_bpermute byte index of the lane one patch row up
-  bool toprow;
-};
-struct T1Win {
-  f32x2_a4 ab, top;
-};
-__device__ __forceinline__ T1Win t1_win_issue(gconst_f32 plane, int base, int sw, const T1Lane &ln) {
-  gconst_bytes p = reinterpret_cast<gconst_bytes>(plane + (base - sw - 1));  // wave-uniform: scalar base + 32-bit offset
-  T1Win w;
-  w.ab = *reinterpret_cast<gconst_f32x2>(p + ln.off_ab);
-  f32x2_a4 z = {0.0f, 0.0f};
-  w.top = z;
-  if (ln.toprow) w.top = *reinterpret_cast<gconst_f32x2>(p + ln.off_top);
-  return w;
-}
-// utilities.cpp:107, the reference's operand order, never contracted (see taps_blend)
-__device__ __forceinline__ float t1_win_blend(const T1Win &w, float w0, float w1, float w2, float w3, const T1Lane &ln) {
-  const float a = w.ab.y, b = w.ab.x;
-  const float cu = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ln.up4, __builtin_bit_cast(int, a)));
-  const float du = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ln.up4, __builtin_bit_cast(int, b)));
-  const float c = ln.toprow ? w.top.y : cu, d = ln.toprow ? w.top.x : du;
-  return w0 * a + w1 * b + w2 * c + w3 * d;
-}
 
-template <int kU> struct T1Loads {  // one pipeline step of the 8x8 iteration phase
-  T1Win cur[kU];
-  float t[kU], gx[kU], gy[kU];
-  int i[kU];  // point index, -1 = padding of a partial step (wave-uniform)
-};
-template <int kU> struct T1RefLoads {  // one pipeline step of the 8x8 level setup
-  T1Win r[kU], x[kU], y[kU];
-  float sgx[kU], sgy[kU], st[kU];  // stale patch of a point that is out of the reference view at this level
-  int i[kU];
-};
-
-// PT = 8: lane == pixel, de-duplicated window rows, no behaviour-changing options (the host routes those to PT = 0);
-// PT = 0: any patch size (run-time e.P), every option.
+// Any patch size (run-time e.P), every option; 8x8 patches without behaviour-changing options take k_track1_p8 below.
 // TL: the level's T/Gx/Gy patches are kept in LDS (they fit); otherwise they are re-read from the global patch
-// buffers, which the same workgroup wrote during the level setup (L2 hits). PN: dopatchnorm (PT = 8 only).
-template <int PT, bool TL, bool PN>
+// buffers, which the same workgroup wrote during the level setup (L2 hits).
+template <bool TL>
 __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args a) {
   extern __shared__ __attribute__((aligned(16))) float sDyn[];
   __shared__ float sPart[kT1MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
@@ -127,7 +88,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = nthr >> 6;
-  const int P = PT ? PT : e.P;
+  const int P = e.P;
   const int n = P * P;
   const int pszd2 = P / 2;
   const int M = e.M;
@@ -177,11 +138,6 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
     const LevelCam lc = a.lc[sl];
     const int sw = lc.sw;
     const PlaneSet pl = e.planes[b * e.nlev + sl];
-    T1Lane ln;
-    ln.off_ab = (unsigned)(((lane >> 3) + 1) * sw + (lane & 7)) * 4u;
-    ln.off_top = (unsigned)(lane & 7) * 4u;
-    ln.up4 = (lane >= 8 ? lane - 8 : lane) << 2;
-    ln.toprow = lane < 8;
     // ---------------------------------------------------------------- level setup, stage A (one point per thread)
     {
       const float *pt2d = e.pt2d + ((size_t)b * e.nlev + sl) * 2 * M;
@@ -217,147 +173,61 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
       float acc[kHUnique];
 #pragma unroll
       for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
-      if constexpr (PT == 8) {
-        gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
-        constexpr int kU = 2;
-        for (int c0 = 0; c0 < mycnt; c0 += 64) {
-          const int cn = min(64, mycnt - c0);
-          const int idx = wave + (c0 + (lane < cn ? lane : 0)) * nwaves;
-          const int mybase = sBase[idx];
-          const int myvis = rec[idx].vis != 0.0f ? 1 : 0;
-          auto issue = [&](T1RefLoads<kU> &L, int k) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-              const bool ok = k + u < cn;
-              const int kk = ok ? k + u : k;
-              const int i = wave + (c0 + kk) * nwaves;
-              const int base = rlane_dyn(mybase, kk);
-              const int vis = rlane_dyn(myvis, kk);
-              L.i[u] = ok ? (vis ? i : i + (1 << 24)) : -1;  // bit 24: out of the reference view (stale patch)
-              if (vis) {  // wave-uniform
-                L.r[u] = t1_win_issue(pref, base, sw, ln);
-                L.x[u] = t1_win_issue(pdx, base, sw, ln);
-                L.y[u] = t1_win_issue(pdy, base, sw, ln);
-              } else {
-                const int o = i * 64 + lane;
-                L.sgx[u] = gGx[o];
-                L.sgy[u] = gGy[o];
-                L.st[u] = gT[o];
-              }
-            }
-          };
-          auto reduce = [&](const T1RefLoads<kU> &L) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-              if (L.i[u] < 0) continue;  // wave-uniform
-              const bool vis = !(L.i[u] & (1 << 24));
-              const int i = L.i[u] & ((1 << 24) - 1);
-              const float4 *r4 = reinterpret_cast<const float4 *>(&rec[i]);
-              const float4 w = r4[0], k0 = r4[1], k1 = r4[2], k2 = r4[3];
-              const int o = i * 64 + lane;
-              float t, gx, gy;
-              if (vis) {
-                t = t1_win_blend(L.r[u], w.x, w.y, w.z, w.w, ln);
-                gx = t1_win_blend(L.x[u], w.x, w.y, w.z, w.w, ln);
-                gy = t1_win_blend(L.y[u], w.x, w.y, w.z, w.w, ln);
-                if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188 (same order as k_ref8)
-                gT[o] = t;
-                gGx[o] = gx;
-                gGy[o] = gy;
-              } else {  // stale patch stays in force (odometer.cpp:304)
-                t = L.st[u];
-                gx = L.sgx[u];
-                gy = L.sgy[u];
-              }
-              if constexpr (TL) {
-                float *d = lTpl + i * 192 + lane;
-                d[0] = t;
-                d[64] = gx;
-                d[128] = gy;
-              }
-              {
-#pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
-                float sd[6];
-                sd[0] = gx * k0.x;
-                sd[1] = gy * k1.y;
-                sd[2] = gx * k0.y + gy * k1.z;
-                sd[3] = gx * k0.z + gy * k1.w;
-                sd[4] = gx * k0.w + gy * k2.x;
-                sd[5] = gx * k1.x + gy * k2.y;
-                int jk = 0;
-#pragma unroll
-                for (int j = 0; j < 6; ++j)
-#pragma unroll
-                  for (int kk = j; kk < 6; ++kk) acc[jk++] += sd[j] * sd[kk];
-              }
-            }
-          };
-          T1RefLoads<kU> A, B;
-          issue(A, 0);
-          for (int k = 0; k < cn; k += 2 * kU) {
-            if (k + kU < cn) issue(B, k + kU);
-            reduce(A);
-            if (k + 2 * kU < cn) issue(A, k + 2 * kU);
-            if (k + kU < cn) reduce(B);
-          }
+      for (int g = wave; g < ngroups; g += nwaves) {
+        const int i = g * ppw + sub;
+        const bool valid = i < npts;
+        const T1Rec r = rec[valid ? i : 0];
+        const bool vis = valid && r.vis != 0.0f;
+        Taps tp;
+        tp.w0 = r.w0; tp.w1 = r.w1; tp.w2 = r.w2; tp.w3 = r.w3;
+        const int base = r.base;
+        float cx[6], cy[6];
+        cx[0] = valid ? r.cx0 : 0.0f; cx[1] = 0.0f; cx[2] = valid ? r.cx2 : 0.0f; cx[3] = valid ? r.cx3 : 0.0f;
+        cx[4] = valid ? r.cx4 : 0.0f; cx[5] = valid ? r.cx5 : 0.0f;
+        cy[0] = 0.0f; cy[1] = valid ? r.cy1 : 0.0f; cy[2] = valid ? r.cy2 : 0.0f; cy[3] = valid ? r.cy3 : 0.0f;
+        cy[4] = valid ? r.cy4 : 0.0f; cy[5] = valid ? r.cy5 : 0.0f;
+        float mean = 0.0f;
+        if (e.dopatchnorm) {  // utilities.cpp:187-188 : intensity patch only
+          float s = 0.0f;
+          for (int q = q0; q < n; q += qstride)
+            if (vis) s += tap4(pl.ref, base + (q / P) * sw + (q % P), sw, tp);
+          s = group_sum(s, gwidth);
+          mean = s / (float)n;
         }
-      } else {
-        for (int g = wave; g < ngroups; g += nwaves) {
-          const int i = g * ppw + sub;
-          const bool valid = i < npts;
-          const T1Rec r = rec[valid ? i : 0];
-          const bool vis = valid && r.vis != 0.0f;
-          Taps tp;
-          tp.w0 = r.w0; tp.w1 = r.w1; tp.w2 = r.w2; tp.w3 = r.w3;
-          const int base = r.base;
-          float cx[6], cy[6];
-          cx[0] = valid ? r.cx0 : 0.0f; cx[1] = 0.0f; cx[2] = valid ? r.cx2 : 0.0f; cx[3] = valid ? r.cx3 : 0.0f;
-          cx[4] = valid ? r.cx4 : 0.0f; cx[5] = valid ? r.cx5 : 0.0f;
-          cy[0] = 0.0f; cy[1] = valid ? r.cy1 : 0.0f; cy[2] = valid ? r.cy2 : 0.0f; cy[3] = valid ? r.cy3 : 0.0f;
-          cy[4] = valid ? r.cy4 : 0.0f; cy[5] = valid ? r.cy5 : 0.0f;
-          float mean = 0.0f;
-          if (e.dopatchnorm) {  // utilities.cpp:187-188 : intensity patch only
-            float s = 0.0f;
-            for (int q = q0; q < n; q += qstride)
-              if (vis) s += tap4(pl.ref, base + (q / P) * sw + (q % P), sw, tp);
-            s = group_sum(s, gwidth);
-            mean = s / (float)n;
-          }
-          for (int q = q0; q < n; q += qstride) {
-            float t = 0.0f, gx = 0.0f, gy = 0.0f;
-            const size_t o = (size_t)i * n + q;
-            if (vis) {
-              const int idx = base + (q / P) * sw + (q % P);
-              t = tap4(pl.ref, idx, sw, tp);
-              if (e.dopatchnorm) t -= mean;
-              gx = tap4(pl.dx, idx, sw, tp);
-              gy = tap4(pl.dy, idx, sw, tp);
-              gT[o] = t;
-              gGx[o] = gx;
-              gGy[o] = gy;
-            } else if (valid) {
-              if (e.robust & ICTR_ROBUST_CLEAN) {  // option: no stale contributions
-                gGx[o] = 0.0f;
-                gGy[o] = 0.0f;
-              } else {
-                gx = gGx[o];
-                gy = gGy[o];
-              }
-              if (TL) t = gT[o];
+        for (int q = q0; q < n; q += qstride) {
+          float t = 0.0f, gx = 0.0f, gy = 0.0f;
+          const size_t o = (size_t)i * n + q;
+          if (vis) {
+            const int idx = base + (q / P) * sw + (q % P);
+            t = tap4(pl.ref, idx, sw, tp);
+            if (e.dopatchnorm) t -= mean;
+            gx = tap4(pl.dx, idx, sw, tp);
+            gy = tap4(pl.dy, idx, sw, tp);
+            gT[o] = t;
+            gGx[o] = gx;
+            gGy[o] = gy;
+          } else if (valid) {
+            if (e.robust & ICTR_ROBUST_CLEAN) {  // option: no stale contributions
+              gGx[o] = 0.0f;
+              gGy[o] = 0.0f;
+            } else {
+              gx = gGx[o];
+              gy = gGy[o];
             }
-            if (TL && valid) {
-              lT[o] = t;
-              lGx[o] = gx;
-              lGy[o] = gy;
-            }
-            float sd[6];
-            sd_values(gx, gy, cx, cy, sd);
-            int jk = 0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-              for (int k = j; k < 6; ++k) acc[jk++] += sd[j] * sd[k];
+            if (TL) t = gT[o];
           }
+          if (TL && valid) {
+            lT[o] = t;
+            lGx[o] = gx;
+            lGy[o] = gy;
+          }
+          float sd[6];
+          sd_values(gx, gy, cx, cy, sd);
+          int jk = 0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int k = j; k < 6; ++k) acc[jk++] += sd[j] * sd[k];
         }
       }
       T1_REDUCE_STORE(kHUnique, acc, sPart[wave])
@@ -408,98 +278,39 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
       float acc[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
-      if constexpr (PT == 8) {
-        gconst_f32 curg = (gconst_f32)cur;
-        constexpr int kU = 2;
-        for (int c0 = 0; c0 < mycnt; c0 += 64) {
-          const int cn = min(64, mycnt - c0);
-          const int mybase = sBase[wave + (c0 + (lane < cn ? lane : 0)) * nwaves];
-          auto issue = [&](T1Loads<kU> &L, int k) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-              const bool ok = k + u < cn;
-              const int kk = ok ? k + u : k;
-              const int i = wave + (c0 + kk) * nwaves;
-              L.i[u] = ok ? i : -1;
-              L.cur[u] = t1_win_issue(curg, rlane_dyn(mybase, kk), sw, ln);
-              if constexpr (TL) {
-                const float *tp = lTpl + i * 192 + lane;
-                L.t[u] = tp[0];
-                L.gx[u] = tp[64];
-                L.gy[u] = tp[128];
-              } else {
-                const int o = i * 64 + lane;
-                L.t[u] = gT[o];
-                L.gx[u] = gGx[o];
-                L.gy[u] = gGy[o];
-              }
-            }
-          };
-          auto reduce = [&](const T1Loads<kU> &L) {
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-              if (L.i[u] < 0) continue;  // wave-uniform
-              const float4 *r4 = reinterpret_cast<const float4 *>(&rec[L.i[u]]);
-              const float4 w = r4[0], k0 = r4[1], k1 = r4[2], k2 = r4[3];
-              float inew = t1_win_blend(L.cur[u], w.x, w.y, w.z, w.w, ln);
-              if constexpr (PN) inew -= wave_sum_dpp(inew) / 64.0f;  // utilities.cpp:111-112
-              const float r = (L.t[u] - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 out of the new view
-              {
-#pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only
-                const float gr = L.gx[u] * r, hr = L.gy[u] * r;
-                acc[0] += gr * k0.x;                // sd1 = Gx cx0
-                acc[1] += hr * k1.y;                // sd2 = Gy cy1
-                acc[2] += gr * k0.y + hr * k1.z;    // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
-                acc[3] += gr * k0.z + hr * k1.w;
-                acc[4] += gr * k0.w + hr * k2.x;
-                acc[5] += gr * k1.x + hr * k2.y;
-              }
-            }
-          };
-          T1Loads<kU> A, B;
-          issue(A, 0);
-          for (int k = 0; k < cn; k += 2 * kU) {
-            if (k + kU < cn) issue(B, k + kU);
-            reduce(A);
-            if (k + 2 * kU < cn) issue(A, k + 2 * kU);
-            if (k + kU < cn) reduce(B);
-          }
+      for (int g = wave; g < ngroups; g += nwaves) {
+        const int i = g * ppw + sub;
+        const bool valid = i < npts;
+        const T1Rec r = rec[valid ? i : 0];
+        const bool vis = valid && r.vis != 0.0f;
+        Taps tp;
+        tp.w0 = r.w0; tp.w1 = r.w1; tp.w2 = r.w2; tp.w3 = r.w3;
+        const int base = r.base;
+        float cx[6], cy[6];
+        cx[0] = r.cx0; cx[1] = 0.0f; cx[2] = r.cx2; cx[3] = r.cx3; cx[4] = r.cx4; cx[5] = r.cx5;
+        cy[0] = 0.0f; cy[1] = r.cy1; cy[2] = r.cy2; cy[3] = r.cy3; cy[4] = r.cy4; cy[5] = r.cy5;
+        float mean = 0.0f;
+        if (e.dopatchnorm) {  // utilities.cpp:111-112
+          float s = 0.0f;
+          for (int q = q0; q < n; q += qstride)
+            if (vis) s += tap4(cur, base + (q / P) * sw + (q % P), sw, tp);
+          s = group_sum(s, gwidth);
+          mean = s / (float)n;
         }
-      } else {
-        for (int g = wave; g < ngroups; g += nwaves) {
-          const int i = g * ppw + sub;
-          const bool valid = i < npts;
-          const T1Rec r = rec[valid ? i : 0];
-          const bool vis = valid && r.vis != 0.0f;
-          Taps tp;
-          tp.w0 = r.w0; tp.w1 = r.w1; tp.w2 = r.w2; tp.w3 = r.w3;
-          const int base = r.base;
-          float cx[6], cy[6];
-          cx[0] = r.cx0; cx[1] = 0.0f; cx[2] = r.cx2; cx[3] = r.cx3; cx[4] = r.cx4; cx[5] = r.cx5;
-          cy[0] = 0.0f; cy[1] = r.cy1; cy[2] = r.cy2; cy[3] = r.cy3; cy[4] = r.cy4; cy[5] = r.cy5;
-          float mean = 0.0f;
-          if (e.dopatchnorm) {  // utilities.cpp:111-112
-            float s = 0.0f;
-            for (int q = q0; q < n; q += qstride)
-              if (vis) s += tap4(cur, base + (q / P) * sw + (q % P), sw, tp);
-            s = group_sum(s, gwidth);
-            mean = s / (float)n;
-          }
-          for (int q = q0; q < n; q += qstride) {
-            if (vis) {
-              const size_t o = (size_t)i * n + q;
-              float inew = tap4(cur, base + (q / P) * sw + (q % P), sw, tp);
-              if (e.dopatchnorm) inew -= mean;
-              float rr = (TL ? lT[o] : gT[o]) - inew;  // pdiff (odometer.cpp:381)
-              if (e.robust & ICTR_ROBUST_HUBER) {
-                const float ar = fabsf(rr);
-                if (ar > e.huber_k) rr *= e.huber_k / ar;
-              }
-              float sd[6];
-              sd_values(TL ? lGx[o] : gGx[o], TL ? lGy[o] : gGy[o], cx, cy, sd);
-#pragma unroll
-              for (int k = 0; k < 6; ++k) acc[k] += sd[k] * rr;  // sd*_proj summed (odometer.cpp:386-404)
+        for (int q = q0; q < n; q += qstride) {
+          if (vis) {
+            const size_t o = (size_t)i * n + q;
+            float inew = tap4(cur, base + (q / P) * sw + (q % P), sw, tp);
+            if (e.dopatchnorm) inew -= mean;
+            float rr = (TL ? lT[o] : gT[o]) - inew;  // pdiff (odometer.cpp:381)
+            if (e.robust & ICTR_ROBUST_HUBER) {
+              const float ar = fabsf(rr);
+              if (ar > e.huber_k) rr *= e.huber_k / ar;
             }
+            float sd[6];
+            sd_values(TL ? lGx[o] : gGx[o], TL ? lGy[o] : gGy[o], cx, cy, sd);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += sd[k] * rr;  // sd*_proj summed (odometer.cpp:386-404)
           }
         }
       }
@@ -994,8 +805,8 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
     return tl ? launch_t1(&k_track1_p8<true, false>, &g[2], e, a, waves, lds, s)
               : launch_t1(&k_track1_p8<false, false>, &g[3], e, a, waves, lds, s);
   }
-  return tl ? launch_t1(&k_track1<0, true, false>, &g[4], e, a, waves, lds, s)
-            : launch_t1(&k_track1<0, false, false>, &g[5], e, a, waves, lds, s);
+  return tl ? launch_t1(&k_track1<true>, &g[4], e, a, waves, lds, s)
+            : launch_t1(&k_track1<false>, &g[5], e, a, waves, lds, s);
 }
 
 }  // namespace ictr
