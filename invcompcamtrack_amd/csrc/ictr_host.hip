@@ -38,7 +38,8 @@ void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, i
 void launch_iter_tail(const EngineDev &, int, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
-hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, hipStream_t);
+hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t);
+size_t track1_blob_bytes(void);
 size_t track1_plan(int, int, int, int *);
 }  // namespace ictr
 
@@ -738,7 +739,8 @@ struct ictr_batch {
   int evk_iters = 0;
   int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
   int maxpts = 0;    // largest nopoints over the problems of the current tracking (set by ictr_batch_begin)
-  int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip), 2: launches replayed as a graph
+  int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip), 2: launches replayed as a graph,
+                     // 3: one-launch tracker that also carried the begin phase and wrote the host mirror
   // the per-iteration launch sequence of one tracking as an instantiated hipGraph (launch-bound sizes, enqueue_levels)
   hipGraphExec_t gexec = nullptr;
   std::string gkey;               // everything the captured launches depend on; a change rebuilds the graph
@@ -750,6 +752,7 @@ struct ictr_batch {
   // the end, so that get_poses / the timing getters wait for THIS tracking only and the caller may already have
   // enqueued the next one on the same stream (another engine): the host runs one step ahead of the GPU
   ProbState *h_st_pin = nullptr;
+  ProbState *d_st_mirror = nullptr;  // h_st_pin as the device sees it (the one-launch tracker stores final states there)
   char *h_up_pin = nullptr;  // pinned staging of the per-tracking uploads (states + plane table): truly asynchronous
   hipEvent_t done_ev = nullptr, up_ev = nullptr;
   bool done_valid = false, up_pending = false;
@@ -870,6 +873,10 @@ extern "C" int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ic
   if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_st_pin, sizeof(ProbState) * B, hipHostMallocDefault);
   if (e == hipSuccess)
     e = hipHostMalloc((void **)&b->h_up_pin, sizeof(ProbState) * B + sizeof(PlaneSet) * B * L, hipHostMallocDefault);
+  if (e == hipSuccess && hipHostGetDevicePointer((void **)&b->d_st_mirror, b->h_st_pin, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    b->d_st_mirror = nullptr;  // no mapped view: final states come back by copy
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&b->up_ev, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -1012,9 +1019,8 @@ extern "C" int ictr_batch_setpose_all(ictr_batch *b, const double *p_all, const 
   return ICTR_OK;
 }
 
-// upload poses + plane tables, zero the tickets, run step 3 for every problem
-extern "C" int ictr_batch_begin(ictr_batch *b) {
-  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+// ictr_batch_begin, host part: initial states, plane table and launch geometry of the coming tracking
+static int begin_prepare(ictr_batch *b) {
   if (int rc = check_op(b->op, b->cam)) return rc;
   if (b->op->maxpttrack != b->M || b->op->psz != b->P || b->op->lv_f + 1 != b->nlev)
     return fail(ICTR_ERR_STATE, "optparam maxpttrack/psz/lv_f changed after creation");
@@ -1063,6 +1069,11 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
     if (b->gridx8 >= 64 && !getenv("ICTR_NO_XCD_BANDS"))  // multiple of 8: XCD-aware order (xcd_band_block)
       b->gridx8 = (int)std::min<int64_t>((b->gridx8 + 7) / 8 * 8, capx / 8 * 8);
   }
+  return ICTR_OK;
+}
+// ... device part: upload states + plane table, clear the trace counter, run step 3 for every problem
+static int begin_device(ictr_batch *b) {
+  const int maxpts = b->maxpts;
   {
     const size_t nst = sizeof(ProbState) * b->B, npl = sizeof(PlaneSet) * b->h_planes.size();
     if (b->up_pending) HIPCHK(hipEventSynchronize(b->up_ev));  // the previous upload has left the staging buffer
@@ -1080,6 +1091,12 @@ extern "C" int ictr_batch_begin(ictr_batch *b) {
     launch_project_ref(engine_dev(b), cams, maxpts, b->stream);
   }
   HIPCHK(hipGetLastError());
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_begin(ictr_batch *b) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (int rc = begin_prepare(b)) return rc;
+  if (int rc = begin_device(b)) return rc;
   b->projected = true;
   return ICTR_OK;
 }
@@ -1263,7 +1280,7 @@ static int enqueue_levels(ictr_batch *b) {
   if (use_track1(b)) {
     LevelCam cams[16];
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
-    HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), b->stream));
+    HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream));
     b->last_path = 1;
     return ICTR_OK;
   }
@@ -1282,15 +1299,48 @@ static int enqueue_levels(ictr_batch *b) {
   return ICTR_OK;
 }
 
-extern "C" int ictr_batch_track_async(ictr_batch *b) {
-  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
-  if (b->sharded) return fail(ICTR_ERR_STATE, "sharded batches are driven phase by phase (see ictr.h)");
-  if (int rc = ictr_batch_begin(b)) return rc;
-  if (int rc = enqueue_levels(b)) return rc;
-  HIPCHK(hipMemcpyAsync(b->h_st_pin, b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
+// One tracking of every problem, enqueued on the stream up to and including the final states' way into the pinned host
+// mirror and the event that marks them. When SetPose has not been followed by an explicit begin and the one-launch
+// tracker is the form to use, a small batch goes out as ONE launch that also carries ictr_batch_begin's device part in
+// its arguments (T1Args in ictr_track1.hip) and writes the final states to the mirror itself: no upload copies, no fill,
+// no projection launch, no read-back copy. Variant bit 18 (262144) keeps the separate operations (A/B).
+static int track_enqueue(ictr_batch *b) {
+  bool fused = false;
+  if (!b->projected) {
+    if (int rc = begin_prepare(b)) return rc;
+    const size_t nst = sizeof(ProbState) * b->B, npl = sizeof(PlaneSet) * b->h_planes.size();
+    fused = use_track1(b) && !b->trace_on && b->d_st_mirror && nst + npl <= track1_blob_bytes() &&
+            !(engine_variant(b) & (1 << 18));
+    if (!fused)
+      if (int rc = begin_device(b)) return rc;
+    b->projected = true;
+  }
+  bool mirrored = false;
+  if (fused) {
+    const size_t nst = sizeof(ProbState) * b->B, npl = sizeof(PlaneSet) * b->h_planes.size();
+    unsigned char blob[4096];
+    memcpy(blob, b->h_st.data(), nst);
+    memcpy(blob + nst, b->h_planes.data(), npl);
+    LevelCam cams[16];
+    for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
+    HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream));
+    b->last_path = 3;
+    mirrored = true;
+  } else if (int rc = enqueue_levels(b)) {
+    return rc;
+  }
+  if (!mirrored)
+    HIPCHK(hipMemcpyAsync(b->h_st_pin, b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipEventRecord(b->done_ev, b->stream));
   b->done_valid = true;
   return ICTR_OK;
+}
+
+extern "C" int ictr_batch_track_async(ictr_batch *b) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (b->sharded) return fail(ICTR_ERR_STATE, "sharded batches are driven phase by phase (see ictr.h)");
+  b->projected = false;  // a batch tracking always starts from the poses of the last SetPose calls
+  return track_enqueue(b);
 }
 // wait for the engine's last tracking (not for whatever else was enqueued on the stream after it)
 static int batch_wait(ictr_batch *b) {
@@ -1493,8 +1543,9 @@ extern "C" int ictr_odometer_setpose(ictr_odometer *o, const double *p_in, const
   o->pose->varval = ph.varval;
   memcpy(o->pose->p, ph.p, sizeof(ph.p));
   memcpy(o->pose->G, ph.G, sizeof(ph.G));
-  // step 3 now, so Get2DPoints is valid right after SetPose like in the reference
-  return ictr_batch_begin(o->b);
+  // Step 3 (the projections) is deferred to whoever needs it first: Get2DPoints right after SetPose runs it on its own
+  // (ictr_batch_get2dpoints), TrackPose folds it into its launch (track_enqueue). Argument errors surface here.
+  return begin_prepare(o->b);
 }
 extern "C" int ictr_odometer_setpose_host(ictr_odometer *o, const double *p_in, const float **img_ref,
                                           const float **img_ref_dx, const float **img_ref_dy, const float **img_new) {
@@ -1516,16 +1567,14 @@ extern "C" int ictr_odometer_trackpose(ictr_odometer *o, double *p_out) {
   if (!o || !p_out) return fail(ICTR_ERR_INVALID, "trackpose: NULL argument");
   ictr_batch *b = o->b;
   if (!b->probs[0].pose_set) return fail(ICTR_ERR_STATE, "TrackPose before SetPose");
-  if (!b->projected)
-    if (int rc = ictr_batch_begin(b)) return rc;
   // verbosity == 2: the reference prints |delta_p|_1 after every iteration (odometer.cpp:416-417); the device
   // records every iteration (trace), printed below in the reference's format
   const bool verbose = b->op->verbosity == 2, trace_was_on = b->trace_on;
   if (verbose && !trace_was_on) {
     b->trace_on = true;
-    HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));
+    if (b->projected) HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));  // else: the begin phase
   }
-  int rc_enq = enqueue_levels(b);
+  int rc_enq = track_enqueue(b);
   b->trace_on = trace_was_on;
   if (rc_enq) return rc_enq;
   // like the reference, a second TrackPose without SetPose continues from the current pose with the old
@@ -1593,6 +1642,12 @@ extern "C" int ictr_batch_read_buffer(ictr_batch *b, int64_t problem, int which,
       }
   }
   if (!src || (size_t)count > avail) return fail(ICTR_ERR_INVALID, "read_buffer: unknown buffer or count too large");
+  if (!b->projected && (which == 5 || which == 8 || which >= 100)) {  // what SetPose's deferred step 3 produces
+    bool all_set = true;
+    for (const ProbHost &ph : b->probs) all_set = all_set && ph.pose_set;
+    if (all_set)
+      if (int rc = ictr_batch_begin(b)) return rc;
+  }
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(host_out, src, sizeof(float) * count, hipMemcpyDeviceToHost));
   return ICTR_OK;

@@ -25,6 +25,8 @@
 // and the per-point records never leave LDS. Independent problems (run_track_nposes' pose samples) are the grid.
 // Arithmetic: identical expressions to the per-iteration kernels (same helpers, -ffp-contract=off), so patches,
 // projections and coefficients are bit-identical to the CPU path; H and b differ from it by summation order only.
+#include <string.h>
+
 #include <algorithm>
 
 #include "ictr_dev.h"
@@ -35,11 +37,86 @@ namespace ictr {
 
 constexpr int kT1MaxWaves = 8;  // 512 threads: two waves per SIMD with up to 256 registers each
 
+// A tracking of one small frame pair is ~270 us of kernel behind ~40 us of dependent small operations (two state
+// uploads, a fill, the projection kernel) and in front of a read-back copy. For batches whose upload fits the kernel
+// argument segment the launch carries the upload itself (`blob`: the initial ProbState of every problem and the plane
+// table, byte for byte what ictr_batch_begin would copy), workgroup b stores its problem's part to device memory for
+// later readers, runs step 3 (k_project_ref's arithmetic) for its own points, and at the end writes the final state
+// straight into the host's pinned mirror as well: one launch and one event per tracking.
+constexpr int kT1BlobWords = 704;  // 2816 B: 4 problems x (ProbState 496 B + 5 levels x 40 B)
 struct T1Args {
   LevelCam lc[16];
   int npts_cap;  // record / LDS template capacity in points (>= every problem's npts)
   int dbg;       // ICTR_T1_PROF builds: ablation bits (env ICTR_T1_DBG); otherwise unused
+  int fused_begin;         // 1: `blob` is valid and this launch does ictr_batch_begin's device part too
+  int st_words, pl_words;  // dwords per problem of the blob's two sections
+  int pad_;
+  ProbState *host_st;      // pinned host mirror of the final states [B], or nullptr
+  __attribute__((aligned(8))) unsigned blob[kT1BlobWords];  // [ProbState x B][PlaneSet x B x nlev]
 };
+
+// Initial state / plane table of problem b: from the kernel arguments (fused begin) or from device memory. The source
+// is chosen at run time, so these few loads are flat loads into vector registers; v_readfirstlane puts every value back
+// into a scalar register (all lanes hold the same value), so plane pointers and the pose stay wave-uniform operands.
+__device__ __forceinline__ int t1_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float t1_uni(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ const float *t1_uni(const float *p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ const ProbState *t1_initial_state(const EngineDev &e, const T1Args &a, int b) {
+  return a.fused_begin ? reinterpret_cast<const ProbState *>(a.blob + (size_t)b * a.st_words) : e.st + b;
+}
+__device__ __forceinline__ PlaneSet t1_planes(const EngineDev &e, const T1Args &a, int b, int level) {
+  // (fused begin: read from the kernel arguments, not back from the table this workgroup has just stored: the scalar
+  // cache is not coherent with vector stores of the same launch)
+  const PlaneSet *tab = a.fused_begin ? reinterpret_cast<const PlaneSet *>(a.blob + (size_t)e.B * a.st_words)
+                                      : e.planes;
+  const PlaneSet v = tab[b * e.nlev + level];
+  PlaneSet r;
+  r.ref = t1_uni(v.ref);
+  r.dx = t1_uni(v.dx);
+  r.dy = t1_uni(v.dy);
+  r.cur = t1_uni(v.cur);
+  r.pack = t1_uni(v.pack);
+  return r;
+}
+// ictr_batch_begin's device part for problem b: state + plane table to device memory, then step 3 for every level
+// (pose.cpp:400-488 at lv_f, pose.cpp:307-397 below it; the camera-frame point is level independent)
+__device__ __forceinline__ void t1_fused_begin(const EngineDev &e, const T1Args &a, int b, int tid, int nthr) {
+  const unsigned *bs = a.blob + (size_t)b * a.st_words;
+  unsigned *ds = reinterpret_cast<unsigned *>(e.st + b);
+  for (int i = tid; i < a.st_words; i += nthr) ds[i] = bs[i];
+  const unsigned *bp = a.blob + (size_t)e.B * a.st_words + (size_t)b * a.pl_words;
+  unsigned *dp = reinterpret_cast<unsigned *>(const_cast<PlaneSet *>(e.planes) + (size_t)b * e.nlev);
+  for (int i = tid; i < a.pl_words; i += nthr) dp[i] = bp[i];
+  const ProbState *st = reinterpret_cast<const ProbState *>(bs);
+  const int npts = st->npts;
+  float G[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) G[k] = st->G[k];
+  const float *p3 = e.pt3d + (size_t)b * 3 * e.M;
+  float *p3r = e.pt3d_ref + (size_t)b * 3 * e.M;
+  for (int i = tid; i < npts; i += nthr) {
+    const float X = p3[i], Y = p3[i + e.M], Z = p3[i + 2 * e.M];
+    const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
+    const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
+    const float tz = G[8] * X + G[9] * Y + G[10] * Z + G[11];
+    p3r[i] = tx;
+    p3r[i + e.M] = ty;
+    p3r[i + 2 * e.M] = tz;
+    for (int l = e.lv_l; l <= e.lv_f; ++l) {
+      float *p2 = e.pt2d + ((size_t)b * e.nlev + l) * 2 * e.M;
+      p2[i] = (tx / tz) * a.lc[l].fx + a.lc[l].cx;
+      p2[i + e.M] = (ty / tz) * a.lc[l].fy + a.lc[l].cy;
+    }
+  }
+  __syncthreads();  // the projections are read back by other threads of this workgroup
+}
 
 struct T1Rec {  // 16 floats per point
   float w0, w1, w2, w3;
@@ -73,6 +150,25 @@ static_assert(sizeof(T1Rec) == 64, "record must be one 64-byte row");
 
 typedef const char __attribute__((address_space(1))) *gconst_bytes;
 
+// final state of the problem (the host reads p, G and the iteration count); wave 0 only
+__device__ __forceinline__ void t1_store_final(ProbState &dst, const WaveSolver &S, const float *G, int lane) {
+  if (lane < 6) {
+    dst.p[lane] = S.p;
+    dst.b[lane] = S.b;
+    dst.dp[lane] = S.dp;
+  }
+  if (lane < 36) dst.H[lane] = S.h;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dst.G[k] = G[k];
+    dst.normdp = S.normdp;
+    dst.normdp_init = S.normdp_init;
+    dst.it = S.it;
+    dst.active = S.active;
+    dst.total_iters = S.total_iters;
+  }
+}
+
 // Any patch size (run-time e.P), every option; 8x8 patches without behaviour-changing options take k_track1_p8 below.
 // TL: the level's T/Gx/Gy patches are kept in LDS (they fit); otherwise they are re-read from the global patch
 // buffers, which the same workgroup wrote during the level setup (L2 hits).
@@ -105,20 +201,21 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
   float *lGy = lGx + (size_t)a.npts_cap * n;
   float *lTpl = lT;                              // 8x8 form: [point][T | Gx | Gy][64], one address + fixed offsets
 
-  ProbState &gst = e.st[b];
-  const int npts = gst.npts;
+  if (a.fused_begin) t1_fused_begin(e, a, b, tid, blockDim.x);
+  const ProbState &gst = *t1_initial_state(e, a, b);
+  const int npts = t1_uni(gst.npts);
   // Wave 0 is the solver: LU factors, pose and loop state stay in its registers for the whole tracking
   // (WaveSolver, ictr_devfn.h); the other waves see only cpos_G and the loop flag, through LDS.
   WaveSolver S;
   float G[12];
   S.p = lane < 6 ? gst.p[lane] : 0.0f;
   S.b = S.dp = S.h = 0.0f;
-  S.total_iters = gst.total_iters;
+  S.total_iters = t1_uni(gst.total_iters);
   S.normdp = S.normdp_init = 1e-10f;
   S.it = 0;
   S.active = 0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) G[k] = gst.G[k];
+  for (int k = 0; k < 12; ++k) G[k] = t1_uni(gst.G[k]);
   if (tid < 12) sG[tid] = gst.G[tid];
 
   const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
@@ -137,7 +234,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
   for (int sl = e.lv_f; sl >= e.lv_l; --sl) {
     const LevelCam lc = a.lc[sl];
     const int sw = lc.sw;
-    const PlaneSet pl = e.planes[b * e.nlev + sl];
+    const PlaneSet pl = t1_planes(e, a, b, sl);
     // ---------------------------------------------------------------- level setup, stage A (one point per thread)
     {
       const float *pt2d = e.pt2d + ((size_t)b * e.nlev + sl) * 2 * M;
@@ -333,21 +430,11 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
       __syncthreads();
     }
   }
-  if (wave == 0) {  // final state back to the problem's record (the host reads p, G and the iteration count)
-    if (lane < 6) {
-      gst.p[lane] = S.p;
-      gst.b[lane] = S.b;
-      gst.dp[lane] = S.dp;
-    }
-    if (lane < 36) gst.H[lane] = S.h;
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) gst.G[k] = G[k];
-      gst.normdp = S.normdp;
-      gst.normdp_init = S.normdp_init;
-      gst.it = S.it;
-      gst.active = S.active;
-      gst.total_iters = S.total_iters;
+  if (wave == 0) {  // final state back to the problem's record, and straight to the host's pinned mirror if there is one
+    t1_store_final(e.st[b], S, G, lane);
+    if (a.host_st) {
+      t1_store_final(a.host_st[b], S, G, lane);
+      if (lane == 0) a.host_st[b].npts = npts;
     }
   }
 #ifdef ICTR_T1_PROF
@@ -420,20 +507,21 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
   float4 *lCoef = reinterpret_cast<float4 *>(sDyn);  // [npts_cap][3]: the 10 coefficients of a point (+ 2 pad)
   float *lTpl = sDyn + (size_t)a.npts_cap * 12;      // [point][T | Gx | Gy][64] when TL
 
-  ProbState &gst = e.st[b];
-  const int npts = gst.npts;
+  if (a.fused_begin) t1_fused_begin(e, a, b, tid, blockDim.x);
+  const ProbState &gst = *t1_initial_state(e, a, b);
+  const int npts = t1_uni(gst.npts);
   SolveOpts sopt = solve_opts(e);
   sopt.robust = 0;  // the host routes every behaviour-changing option to the any-size form: no compose / log code here
   WaveSolver S;  // wave 0 is the solver (ictr_devfn.h)
   float G[12];
   S.p = lane < 6 ? gst.p[lane] : 0.0f;
   S.b = S.dp = S.h = 0.0f;
-  S.total_iters = gst.total_iters;
+  S.total_iters = t1_uni(gst.total_iters);
   S.normdp = S.normdp_init = 1e-10f;
   S.it = 0;
   S.active = 0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) G[k] = gst.G[k];
+  for (int k = 0; k < 12; ++k) G[k] = t1_uni(gst.G[k]);
   if (tid < 12) sG[tid] = gst.G[tid];
 
   const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
@@ -458,7 +546,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
   for (int sl = e.lv_f; sl >= e.lv_l; --sl) {
     const LevelCam lc = a.lc[sl];
     const int sw = lc.sw;
-    const PlaneSet pl = e.planes[b * e.nlev + sl];
+    const PlaneSet pl = t1_planes(e, a, b, sl);
     const unsigned off_cd = (unsigned)((lane >> 3) * sw + (lane & 7)) * 4u;  // bytes from the window's top-left texel
     const unsigned off_ab = off_cd + (unsigned)sw * 4u;
     constexpr int kU = 2;   // patches per pipeline step of the level setup
@@ -742,21 +830,11 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
     for (int k = 0; k < 4; ++k) e.partH[(size_t)e.B * 8 + b * 4 + k] = (float)S.tm[k];
   }
 #endif
-  if (wave == 0) {  // final state back to the problem's record (the host reads p, G and the iteration count)
-    if (lane < 6) {
-      gst.p[lane] = S.p;
-      gst.b[lane] = S.b;
-      gst.dp[lane] = S.dp;
-    }
-    if (lane < 36) gst.H[lane] = S.h;
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) gst.G[k] = G[k];
-      gst.normdp = S.normdp;
-      gst.normdp_init = S.normdp_init;
-      gst.it = S.it;
-      gst.active = S.active;
-      gst.total_iters = S.total_iters;
+  if (wave == 0) {  // final state back to the problem's record, and straight to the host's pinned mirror if there is one
+    t1_store_final(e.st[b], S, G, lane);
+    if (a.host_st) {
+      t1_store_final(a.host_st[b], S, G, lane);
+      if (lane == 0) a.host_st[b].npts = npts;
     }
   }
 }
@@ -785,11 +863,27 @@ static hipError_t launch_t1(K kernel, size_t *granted, const EngineDev &e, const
   return hipGetLastError();
 }
 
-hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, int waves, hipStream_t s) {
+// bytes of initial state + plane table a launch can carry in its arguments (fused begin, see T1Args)
+size_t track1_blob_bytes(void) { return sizeof(unsigned) * kT1BlobWords; }
+
+// blob (may be NULL): [ProbState x B][PlaneSet x B x nlev] for the fused begin; host_st (may be NULL): pinned mirror
+hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, int waves, const void *blob,
+                         ProbState *host_st, hipStream_t s) {
   T1Args a;
   for (int l = 0; l < 16; ++l) a.lc[l] = cams[l < e.nlev ? l : 0];
   a.npts_cap = (std::max(maxpts, 1) + 3) & ~3;  // keeps the LDS template arrays 16-byte aligned
   a.dbg = 0;
+  a.pad_ = 0;
+  a.st_words = (int)(sizeof(ProbState) / 4);
+  a.pl_words = (int)(sizeof(PlaneSet) / 4) * e.nlev;
+  a.host_st = host_st;
+  a.fused_begin = 0;
+  if (blob) {
+    const size_t bytes = (size_t)e.B * 4 * (a.st_words + a.pl_words);
+    if (bytes > sizeof(a.blob)) return hipErrorInvalidValue;
+    memcpy(a.blob, blob, bytes);
+    a.fused_begin = 1;
+  }
 #ifdef ICTR_T1_PROF
   if (const char *d = getenv("ICTR_T1_DBG")) a.dbg = atoi(d);
 #endif

@@ -469,7 +469,8 @@ class TrackBatch:
         """Launch form of the last tracking: per-iteration launches (plain, or replayed as one hipGraph) or the
         one-launch small-problem tracker."""
         return {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)",
-                2: "k_iter* (per-iteration launches replayed as one hipGraph)"}.get(
+                2: "k_iter* (per-iteration launches replayed as one hipGraph)",
+                3: "k_track1 (one launch per tracking, begin phase and read-back included)"}.get(
             _lib.load().ictr_batch_last_path(self._h), "?")
 
     def set_reduction_buffer(self, dev_ptr):
