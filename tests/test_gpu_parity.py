@@ -35,6 +35,7 @@ DP_TOL = 2e-3
 
 LAUNCHES = 8192   # variant bit 13: per-iteration launch pairs (k_ref* / k_iter* + tails) whatever the problem size
 ONE_LAUNCH = 16384  # variant bit 14: the one-launch tracker k_track1 (default choice for small problems)
+SEPARATE_BEGIN = 1 << 18  # variant bit 18: uploads, projection launch and read-back copy as separate operations
 NO_GRAPH = 32768  # variant bit 15: the per-iteration launches as plain launches (default below 65 536 points: one hipGraph)
 
 
@@ -298,6 +299,52 @@ def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
     for op in ops:
         op.dopatchnorm, op.normdp_ratio = 0, 0.0
     assert np.array_equal(both(700, 0.0)[0], first[0])
+
+
+@pytest.mark.parametrize("B,psz", [(1, 8), (3, 8), (2, 4), (1, 5)])
+def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz):
+    """Small batches go out as ONE launch that carries ictr_batch_begin's device part in its arguments and writes the
+    final states into the pinned host mirror (track_enqueue): every bit -- poses, iteration counts, the projections
+    Get2DPoints returns, the stored state -- must equal the form with separate uploads / projection launch / copy."""
+    sc = scene(256, 224, 90, seed=40 + psz, margin=float(max(12, psz + 9)))
+    op = ic.optparam(3, 0, psz, 6, 0.0, 0, 0, 90)
+    cam = ic.CamClass(4, sc["fc"], sc["cc"], sc["wh"], psz)
+    pa, pb = ic.Pyramid(sc["img_a"], 3, psz), ic.Pyramid(sc["img_b"], 3, psz)
+    out = []
+    for variant in (0, SEPARATE_BEGIN):
+        e = ic.TrackBatch(cam, op, B)
+        e.set_variant(variant)
+        for k in range(B):
+            e.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :90 - 7 * k].copy()))
+        res = []
+        for rep, (ra, rb) in enumerate(((pa, pb), (pb, pa), (pa, pb))):
+            for k in range(B):
+                e.SetPose(k, sc["p_a"] + 1e-3 * k, ra, rb)
+            e.track_async()
+            res.append((e.poses().copy(), e.iterations().copy(), [e.Get2DPoints(k).copy() for k in range(B)],
+                        [e.read_buffer(k, 8, 40) for k in range(B)]))
+        out.append((res, e.path_name()))
+    assert "begin phase" in out[0][1] and "begin phase" not in out[1][1], (out[0][1], out[1][1])
+    for ra, rb in zip(out[0][0], out[1][0]):
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        assert all(np.array_equal(x, y) for x, y in zip(ra[2], rb[2]))
+        assert all(np.array_equal(x[:18], y[:18]) for x, y in zip(ra[3], rb[3]))  # p, G of the stored state
+    # the reference's single-problem API: Get2DPoints right after SetPose, TrackPose twice without a second SetPose
+    if B == 1:
+        got = []
+        for variant in (0, SEPARATE_BEGIN):
+            cam1 = ic.CamClass(4, sc["fc"], sc["cc"], sc["wh"], psz)
+            pose = ic.PoseClass(cam1, op)
+            odo = ic.OdometerClass(pose, op)
+            odo.set_variant(variant)
+            odo.Set3Dpoints(sc["pts3d"].copy())
+            odo.SetPose(sc["p_a"], pa, pb)
+            p2 = odo.Get2DPoints().copy()
+            odo.SetPose(sc["p_a"], pa, pb)
+            p_first = odo.TrackPose().copy()
+            p_second = odo.TrackPose().copy()   # continues from the pose just found (odometer.cpp: no reset)
+            got.append((p2, p_first, p_second))
+        assert all(np.array_equal(x, y) for x, y in zip(got[0], got[1]))
 
 
 def test_setpose_all_equals_one_setpose_per_problem(oracle):
