@@ -1621,12 +1621,13 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
     if (first && defer_h(e, variant)) {
       if (e.dopatchnorm)
         hipLaunchKernelGGL((k_iter8<true, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
-      else if (ku == 2)
-        hipLaunchKernelGGL((k_iter8<false, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
       else if (ldsel == 1)
         hipLaunchKernelGGL((k_iter8<false, 4, true, true, 0>), g8, blk, 0, s, e, lc, level, cpw);
-      else
+      else if (variant & (1 << 20))  // A/B: four patches per step like the regular launches (116 VGPRs, occupancy 4)
         hipLaunchKernelGGL((k_iter8<false, 4, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      else  // the H-accumulating launch carries 21 more accumulators: two patches per step keep it at 81 VGPRs /
+            // occupancy 5 (r02: 258 -> 195 us wall per 16-pair launch beside the other engine, step 6.34 -> 6.30 ms)
+        hipLaunchKernelGGL((k_iter8<false, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
     } else if (e.dopatchnorm)
       hipLaunchKernelGGL((k_iter8<true, 2, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
