@@ -35,7 +35,8 @@
 
 namespace ictr {
 
-constexpr int kT1MaxWaves = 8;  // 512 threads: two waves per SIMD with up to 256 registers each
+constexpr int kT1MaxWaves = 8;  // any-size form: 512 threads, two waves per SIMD with up to 256 registers each
+constexpr int kT8MaxWaves = 8;  // 8x8 form
 
 // A tracking of one small frame pair is ~270 us of kernel behind ~40 us of dependent small operations (two state
 // uploads, a fill, the projection kernel) and in front of a read-back copy. For batches whose upload fits the kernel
@@ -487,16 +488,23 @@ __device__ __forceinline__ float rl(float v, int k) {  // v_readlane with a wave
 }
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
-template <bool TL, bool PN>
-__global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1Args a) {
+// LEAN: built for 128 registers (four waves per SIMD: TWO workgroups share a CU), one patch per step in the level setup,
+// ~30 spilled registers. A batch of more problems than the chip has CUs runs 20 % faster this way (500 x 60 points:
+// 0.64 -> 0.50 ms); a batch that leaves CUs idle anyway is 5 % faster with the 206-register build (LEAN = false).
+// Same operations in the same order: the two builds give the same bits.
+template <bool TL, bool PN, bool LEAN>
+__global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(EngineDev e, T1Args a) {
   extern __shared__ __attribute__((aligned(16))) float sDyn[];
-  __shared__ float sPart[kT1MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
-  __shared__ float sG[12];                             // cpos_G of the current iteration
-  __shared__ int sActive;                              // loop condition, decided by wave 0
+  __shared__ float sPart[kT8MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
+  // The problem's state (pose, LU factors of the level, loop condition) lives in LDS between the solver's turns: the
+  // solver's ~30 registers are then live in wave 0's tail only, not across every wave's patch loops (the kernel as a
+  // whole stays under 128 VGPRs, so two workgroups -- or sixteen waves -- share a CU). Same helpers, same arithmetic as
+  // the per-iteration tails (k_level_tail / k_iter_tail), which keep the state in device memory.
+  __shared__ ProbState sSt;
   // per wave, per patch of the current chunk: [w1 w0 w3 w2][vis - - -] of the current iteration. Written by the
   // patch's own lane in stage 1, read back as broadcast ds_read_b128 in stage 2: the LDS pipe is idle there, the VALU
   // is the bottleneck (a v_readlane per scalar cost 15 VALU slots per patch)
-  __shared__ __attribute__((aligned(16))) float sRecW[kT1MaxWaves][64 * 8];
+  __shared__ __attribute__((aligned(16))) float sRecW[kT8MaxWaves][64 * 8];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -512,17 +520,11 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
   const int npts = t1_uni(gst.npts);
   SolveOpts sopt = solve_opts(e);
   sopt.robust = 0;  // the host routes every behaviour-changing option to the any-size form: no compose / log code here
-  WaveSolver S;  // wave 0 is the solver (ictr_devfn.h)
-  float G[12];
-  S.p = lane < 6 ? gst.p[lane] : 0.0f;
-  S.b = S.dp = S.h = 0.0f;
-  S.total_iters = t1_uni(gst.total_iters);
-  S.normdp = S.normdp_init = 1e-10f;
-  S.it = 0;
-  S.active = 0;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) G[k] = t1_uni(gst.G[k]);
-  if (tid < 12) sG[tid] = gst.G[tid];
+  {
+    const unsigned *src = reinterpret_cast<const unsigned *>(&gst);
+    unsigned *dst = reinterpret_cast<unsigned *>(&sSt);
+    for (int i = tid; i < (int)(sizeof(ProbState) / 4); i += blockDim.x) dst[i] = src[i];
+  }  // (first read by wave 0 behind the level setup's barrier)
 
   const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
   const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
@@ -540,7 +542,6 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
   unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = 0, t1_ = 0;
   if (tid == 0) t0_ = __builtin_readcyclecounter();
   const int dbg = a.dbg;
-  S.tm[0] = S.tm[1] = S.tm[2] = S.tm[3] = 0;
 #endif
 
   for (int sl = e.lv_f; sl >= e.lv_l; --sl) {
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
     const PlaneSet pl = t1_planes(e, a, b, sl);
     const unsigned off_cd = (unsigned)((lane >> 3) * sw + (lane & 7)) * 4u;  // bytes from the window's top-left texel
     const unsigned off_ab = off_cd + (unsigned)sw * 4u;
-    constexpr int kU = 2;   // patches per pipeline step of the level setup
+    constexpr int kU = LEAN ? 1 : 2;  // patches per pipeline step of the level setup (2: +24 registers)
     constexpr int kUi = 2;  // ... of the iterations (4: 256 VGPRs + spills, no gain; measured r02)
     // ---------------------------------------------------------------- level setup (odometer.cpp:268-334, 428-472)
     {
@@ -629,19 +630,21 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
               d[128] = gy;
             }
             {
-#pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
+              // H = sum sd_j sd_k is compared to tolerance only, so multiply-adds may be fused -- but fused HERE, by
+              // hand, not wherever a build's scheduling happens to allow it: both register budgets of this kernel
+              // (LEAN or not) then produce the same bits
               float sd[6];
               sd[0] = gx * rl(cx[0], kk);
               sd[1] = gy * rl(cy[1], kk);
-              sd[2] = gx * rl(cx[2], kk) + gy * rl(cy[2], kk);
-              sd[3] = gx * rl(cx[3], kk) + gy * rl(cy[3], kk);
-              sd[4] = gx * rl(cx[4], kk) + gy * rl(cy[4], kk);
-              sd[5] = gx * rl(cx[5], kk) + gy * rl(cy[5], kk);
+              sd[2] = __builtin_fmaf(gx, rl(cx[2], kk), gy * rl(cy[2], kk));
+              sd[3] = __builtin_fmaf(gx, rl(cx[3], kk), gy * rl(cy[3], kk));
+              sd[4] = __builtin_fmaf(gx, rl(cx[4], kk), gy * rl(cy[4], kk));
+              sd[5] = __builtin_fmaf(gx, rl(cx[5], kk), gy * rl(cy[5], kk));
               int jk = 0;
 #pragma unroll
               for (int j = 0; j < 6; ++j)
 #pragma unroll
-                for (int q = j; q < 6; ++q) acc[jk++] += sd[j] * sd[q];
+                for (int q = j; q < 6; ++q, ++jk) acc[jk] = __builtin_fmaf(sd[j], sd[q], acc[jk]);
             }
           }
         };
@@ -666,9 +669,10 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
       const int r = lane / 6, c = lane - 6 * r;
       const int lo = r < c ? r : c, hi = r < c ? c : r;
       const int j = lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
+      WaveSolver S;  // wave 0 is the solver (ictr_devfn.h)
       ws_factor(S, lane_gather((float)hs, j), lane);
-      ws_level_reset(S, sopt);
-      if (lane == 0) sActive = S.active;
+      ws_store_factor(S, sSt, lane);
+      if (lane == 0) level_reset(sSt, e);  // odometer.cpp:341-346
     }
     __syncthreads();
     T1_MARK(2)  // H sum + LU
@@ -681,13 +685,13 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
     const bool single = mycnt <= 64;
     float *recw = sRecW[wave];
     const float4 *recw4 = reinterpret_cast<const float4 *>(recw);
-    while (sActive) {  // workgroup-uniform: read after a barrier, rewritten only between barriers
+    while (sSt.active) {  // workgroup-uniform: read after a barrier, rewritten only between barriers
       float acc[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
       float Gc[12];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) Gc[k] = sG[k];
+      for (int k = 0; k < 12; ++k) Gc[k] = sSt.G[k];
       for (int c0 = 0; c0 < mycnt; c0 += 64) {
         const int cn = min(64, mycnt - c0);
         // stage 1: projection at the current pose (pose.cpp:384-391), ind_new (odometer.cpp:369-377)
@@ -781,15 +785,14 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
             float inew = wv[u].y * L.cur[u].ab.y + wv[u].x * L.cur[u].ab.x + wv[u].w * L.cur[u].cd.y + wv[u].z * L.cur[u].cd.x;
             if constexpr (PN) inew -= wave_sum_dpp(inew) / 64.0f;  // utilities.cpp:111-112
             const float r = (L.t[u] - inew) * vf[u];  // pdiff (odometer.cpp:381); 0 out of the new view
-            {
-#pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only
+            {  // the J^T r sums are compared to tolerance only: explicit multiply-adds (see the level setup)
               const float gr = L.gx[u] * r, hr = L.gy[u] * r;
-              acc[0] += gr * q0[u].x;                     // sd1 = Gx cx0
-              acc[1] += hr * q1[u].y;                     // sd2 = Gy cy1
-              acc[2] += gr * q0[u].y + hr * q1[u].z;      // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
-              acc[3] += gr * q0[u].z + hr * q1[u].w;
-              acc[4] += gr * q0[u].w + hr * q2[u].x;
-              acc[5] += gr * q1[u].x + hr * q2[u].y;
+              acc[0] = __builtin_fmaf(gr, q0[u].x, acc[0]);                                  // sd1 = Gx cx0
+              acc[1] = __builtin_fmaf(hr, q1[u].y, acc[1]);                                  // sd2 = Gy cy1
+              acc[2] = __builtin_fmaf(gr, q0[u].y, __builtin_fmaf(hr, q1[u].z, acc[2]));     // sd3..sd6 = Gx cxk + Gy cyk
+              acc[3] = __builtin_fmaf(gr, q0[u].z, __builtin_fmaf(hr, q1[u].w, acc[3]));     // (odometer.cpp:319-326)
+              acc[4] = __builtin_fmaf(gr, q0[u].w, __builtin_fmaf(hr, q2[u].x, acc[4]));
+              acc[5] = __builtin_fmaf(gr, q1[u].x, __builtin_fmaf(hr, q2[u].y, acc[5]));
             }
           }
         };
@@ -812,12 +815,12 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
         double bs = 0.0;
         if (lane < 6)
           for (int w = 0; w < nwaves; ++w) bs += (double)sPart[w][lane];
+        WaveSolver S;
+        float G[12];
+        ws_load_state(S, sSt, lane, G);
+        ws_load_factor(S, sSt, lane);
         ws_iterate(S, (float)bs, sopt, sl, b, lane, G);
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 12; ++k) sG[k] = G[k];
-          sActive = S.active;
-        }
+        ws_store_state(S, sSt, lane, G);
       }
       T1_MARK(6)  // final sum + solve + update
       __syncthreads();
@@ -827,14 +830,16 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
 #ifdef ICTR_T1_PROF
   if (tid == 0) {
     for (int k = 0; k < 8; ++k) e.partH[(size_t)b * 8 + k] = (float)tp_[k];
-    for (int k = 0; k < 4; ++k) e.partH[(size_t)e.B * 8 + b * 4 + k] = (float)S.tm[k];
   }
 #endif
   if (wave == 0) {  // final state back to the problem's record, and straight to the host's pinned mirror if there is one
-    t1_store_final(e.st[b], S, G, lane);
-    if (a.host_st) {
-      t1_store_final(a.host_st[b], S, G, lane);
-      if (lane == 0) a.host_st[b].npts = npts;
+    const unsigned *src = reinterpret_cast<const unsigned *>(&sSt);
+    unsigned *dst = reinterpret_cast<unsigned *>(e.st + b);
+    unsigned *hst = reinterpret_cast<unsigned *>(a.host_st ? a.host_st + b : nullptr);
+    for (int i = lane; i < (int)(sizeof(ProbState) / 4); i += 64) {
+      const unsigned v = src[i];
+      dst[i] = v;
+      if (hst) hst[i] = v;
     }
   }
 }
@@ -844,7 +849,7 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1_p8(EngineDev e, T1A
 size_t track1_plan(int npts_cap, int n, int p8, int *tmpl_lds) {
   const size_t recb = (size_t)npts_cap * (p8 ? 48 : 68);  // 8x8: 12 coefficient floats; else 64-byte record + base
   const size_t tmplb = (size_t)npts_cap * n * 3 * sizeof(float);
-  const size_t budget = 140 * 1024;  // of the CU's 160 KB; the static arrays (sRecW, partial sums) take ~18 KB
+  const size_t budget = 140 * 1024;  // of the CU's 160 KB; the static arrays (sRecW, partial sums, state) take ~18 KB
   *tmpl_lds = (recb + tmplb <= budget) ? 1 : 0;
   return recb + (*tmpl_lds ? tmplb : 0);
 }
@@ -890,14 +895,34 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
   const bool p8 = e.P == 8 && !e.robust;  // the lean 8x8 form; behaviour-changing options run in the any-size form
   int tl = 0;
   const size_t lds = track1_plan(a.npts_cap, e.n, p8 ? 1 : 0, &tl);
-  waves = std::min(std::max(waves, 1), kT1MaxWaves);
-  static size_t g[6] = {0, 0, 0, 0, 0, 0};
+  waves = std::min(std::max(waves, 1), p8 ? kT8MaxWaves : kT1MaxWaves);
+  static size_t g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (p8) {
+    // more workgroups than CUs, and two of them fit one CU's LDS: the 128-register build (see k_track1_p8)
+    int cus = 256;
+    {
+      static const int n_cu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+          v = 256;
+        return v;
+      }();
+      cus = n_cu;
+    }
+    const bool lean = e.B > cus && lds <= 60 * 1024;
+    if (lean) {
+      if (e.dopatchnorm)
+        return tl ? launch_t1(&k_track1_p8<true, true, true>, &g[6], e, a, waves, lds, s)
+                  : launch_t1(&k_track1_p8<false, true, true>, &g[7], e, a, waves, lds, s);
+      return tl ? launch_t1(&k_track1_p8<true, false, true>, &g[8], e, a, waves, lds, s)
+                : launch_t1(&k_track1_p8<false, false, true>, &g[9], e, a, waves, lds, s);
+    }
     if (e.dopatchnorm)
-      return tl ? launch_t1(&k_track1_p8<true, true>, &g[0], e, a, waves, lds, s)
-                : launch_t1(&k_track1_p8<false, true>, &g[1], e, a, waves, lds, s);
-    return tl ? launch_t1(&k_track1_p8<true, false>, &g[2], e, a, waves, lds, s)
-              : launch_t1(&k_track1_p8<false, false>, &g[3], e, a, waves, lds, s);
+      return tl ? launch_t1(&k_track1_p8<true, true, false>, &g[0], e, a, waves, lds, s)
+                : launch_t1(&k_track1_p8<false, true, false>, &g[1], e, a, waves, lds, s);
+    return tl ? launch_t1(&k_track1_p8<true, false, false>, &g[2], e, a, waves, lds, s)
+              : launch_t1(&k_track1_p8<false, false, false>, &g[3], e, a, waves, lds, s);
   }
   return tl ? launch_t1(&k_track1<true>, &g[4], e, a, waves, lds, s)
             : launch_t1(&k_track1<false>, &g[5], e, a, waves, lds, s);

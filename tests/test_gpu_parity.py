@@ -379,6 +379,33 @@ def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz):
         assert all(np.array_equal(x, y) for x, y in zip(got[0], got[1]))
 
 
+def test_one_launch_tracker_gives_the_same_bits_in_both_register_budgets(oracle):
+    """k_track1_p8 exists in two builds: 128 registers (two workgroups per CU; chosen when a batch has more problems than
+    the chip has CUs) and ~200 registers (everything else). Same operations in the same order: a batch of 300 problems
+    (first build) must give exactly the poses of the same problems tracked as two batches of 150 (second build) --
+    which is also what keeps run_track_nposes' output independent of how the samples are split over ranks."""
+    sc = scene(320, 240, 40, seed=61)
+    op = ic.optparam(3, 0, 8, 5, 0.01, 0, 0, 40)
+    cam = ic.CamClass(4, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 3, 8), ic.Pyramid(sc["img_b"], 3, 8)
+    poses = sc["p_a"][None, :] + np.random.default_rng(8).normal(0, 2e-3, (300, 6))
+
+    def run(idx):
+        b = ic.TrackBatch(cam, op, len(idx))
+        for k, i in enumerate(idx):
+            b.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :25 + i % 16].copy()))
+        b.SetPoseAll(poses[idx], pa, pb)
+        b.track_async()
+        out = (b.poses().copy(), b.iterations().copy())
+        assert "k_track1" in b.path_name()
+        return out
+
+    whole = run(np.arange(300))
+    halves = [run(np.arange(0, 150)), run(np.arange(150, 300))]
+    assert np.array_equal(whole[0], np.concatenate([h[0] for h in halves]))
+    assert np.array_equal(whole[1], np.concatenate([h[1] for h in halves]))
+
+
 def test_setpose_all_equals_one_setpose_per_problem(oracle):
     """ictr_batch_setpose_all (one call for every pose sample of a frame pair) == the SetPose loop, bit for bit."""
     sc = scene(320, 240, 60, seed=31)
