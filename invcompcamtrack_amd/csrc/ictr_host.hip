@@ -40,7 +40,7 @@ void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
 hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t);
 size_t track1_blob_bytes(void);
-size_t track1_plan(int, int, int, int *);
+size_t track1_plan(int, int, int, int, int *);
 }  // namespace ictr
 
 namespace ictr {

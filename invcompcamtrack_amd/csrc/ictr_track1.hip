@@ -51,7 +51,7 @@ struct T1Args {
   int dbg;       // ICTR_T1_PROF builds: ablation bits (env ICTR_T1_DBG); otherwise unused
   int fused_begin;         // 1: `blob` is valid and this launch does ictr_batch_begin's device part too
   int st_words, pl_words;  // dwords per problem of the blob's two sections
-  int pad_;
+  int cap_w;               // 8x8 form: LDS slots per wave (>= its points, rounded up to whole pipeline steps + prefetch)
   ProbState *host_st;      // pinned host mirror of the final states [B], or nullptr
   __attribute__((aligned(8))) unsigned blob[kT1BlobWords];  // [ProbState x B][PlaneSet x B x nlev]
 };
@@ -501,10 +501,6 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
   // whole stays under 128 VGPRs, so two workgroups -- or sixteen waves -- share a CU). Same helpers, same arithmetic as
   // the per-iteration tails (k_level_tail / k_iter_tail), which keep the state in device memory.
   __shared__ ProbState sSt;
-  // per wave, per patch of the current chunk: [w1 w0 w3 w2][vis - - -] of the current iteration. Written by the
-  // patch's own lane in stage 1, read back as broadcast ds_read_b128 in stage 2: the LDS pipe is idle there, the VALU
-  // is the bottleneck (a v_readlane per scalar cost 15 VALU slots per patch)
-  __shared__ __attribute__((aligned(16))) float sRecW[kT8MaxWaves][64 * 8];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -512,8 +508,17 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = blockDim.x >> 6;
   const int M = e.M;
-  float4 *lCoef = reinterpret_cast<float4 *>(sDyn);  // [npts_cap][3]: the 10 coefficients of a point (+ 2 pad)
-  float *lTpl = sDyn + (size_t)a.npts_cap * 12;      // [point][T | Gx | Gy][64] when TL
+  // Wave-major LDS layout: wave w owns the slots [w cap_w, (w + 1) cap_w); its j-th point (i = w + j nwaves) is slot
+  // w cap_w + j. Per slot one 64-byte record [w1 w0 w3 w2][cx2 cx3 cx4 cx5][cy2 cy3 cy4 cy5][cx0 cy1 vis -] -- the
+  // weights and the visibility flag rewritten by the point's own lane in every iteration's stage 1, the ten non-zero
+  // steepest-descent coefficients once per level -- and (TL) the patch [T | Gx | Gy][64]. Stage 2 walks a wave's slots
+  // with ONE running address each: four broadcast ds_read_b128 and three ds_read_b32 at immediate offsets per patch, no
+  // index arithmetic. The slots behind a wave's last point stay zero (weights, flag, patches): the patch loop runs in
+  // whole pipeline steps and prefetches past the end without a single bounds check.
+  const int cap_w = a.cap_w;
+  float4 *lRec = reinterpret_cast<float4 *>(sDyn);                      // [nwaves * cap_w][4]
+  float *lTpl = sDyn + (size_t)nwaves * cap_w * 16;                    // [nwaves * cap_w][T | Gx | Gy][64] when TL
+  const int slot0 = wave * cap_w;
 
   if (a.fused_begin) t1_fused_begin(e, a, b, tid, blockDim.x);
   const ProbState &gst = *t1_initial_state(e, a, b);
@@ -525,6 +530,11 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
     unsigned *dst = reinterpret_cast<unsigned *>(&sSt);
     for (int i = tid; i < (int)(sizeof(ProbState) / 4); i += blockDim.x) dst[i] = src[i];
   }  // (first read by wave 0 behind the level setup's barrier)
+  {  // records and patches start as zeros: what the padding slots stay for the whole tracking
+    const int nz = nwaves * cap_w * (TL ? 16 + 192 : 16);
+    for (int i = tid; i < nz; i += blockDim.x) sDyn[i] = 0.0f;
+    __syncthreads();
+  }
 
   const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
   const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
@@ -578,14 +588,21 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
           cx[0] = a0.x; cx[1] = a0.y; cx[2] = a0.z; cx[3] = a0.w; cx[4] = a1.x; cx[5] = a1.y;
           cy[0] = a1.z; cy[1] = a1.w; cy[2] = a2.x; cy[3] = a2.y; cy[4] = a2.z; cy[5] = a2.w;
         }
-        if (pv) {  // for the iterations' stage 1
-          lCoef[ip * 3 + 0] = make_float4(cx[0], cx[2], cx[3], cx[4]);
-          lCoef[ip * 3 + 1] = make_float4(cx[5], cy[1], cy[2], cy[3]);
-          lCoef[ip * 3 + 2] = make_float4(cy[4], cy[5], 0.0f, 0.0f);
-        }
         const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
         const int base_v = (tp.row0 - 1) * sw + tp.col0 - 1;
         const int vis_v = vis ? 1 : 0;
+        float4 *const recs = lRec + (size_t)(slot0 + c0) * 4;  // this chunk's records
+        if (pv) {  // the level's coefficients into the point's record; for stage B below also the REFERENCE window's
+                   // weights (slot 0: every iteration's stage 1 rewrites it, and the flag in slot 3, for the current frame)
+          float4 *r4 = recs + lane * 4;
+          r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
+          r4[1] = make_float4(cx[2], cx[3], cx[4], cx[5]);
+          r4[2] = make_float4(cy[2], cy[3], cy[4], cy[5]);
+          r4[3] = make_float4(cx[0], cy[1], 0.0f, 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         auto issue = [&](T8RefLoads<kU> &L, int k) {
 #pragma unroll
           for (int u = 0; u < kU; ++u) {
@@ -609,11 +626,13 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
             const int i = wave + (c0 + kk) * nwaves;
             const int o = i * 64 + lane;
             float t, gx, gy;
+            const float4 *r4 = recs + kk * 4;  // broadcast reads: one address, immediate offsets
+            const float4 qx = r4[1], qy = r4[2], qz = r4[3];
             if (!(L.k[u] & 256)) {
-              const float w0 = rl(tp.w0, kk), w1 = rl(tp.w1, kk), w2 = rl(tp.w2, kk), w3 = rl(tp.w3, kk);
-              t = t8_blend(L.r[u], w0, w1, w2, w3);
-              gx = t8_blend(L.x[u], w0, w1, w2, w3);
-              gy = t8_blend(L.y[u], w0, w1, w2, w3);
+              const float4 w = r4[0];
+              t = t8_blend(L.r[u], w.x, w.y, w.z, w.w);
+              gx = t8_blend(L.x[u], w.x, w.y, w.z, w.w);
+              gy = t8_blend(L.y[u], w.x, w.y, w.z, w.w);
               if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188 (same order as k_ref8)
               gT[o] = t;
               gGx[o] = gx;
@@ -624,7 +643,7 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
               gy = gGy[o];
             }
             if constexpr (TL) {
-              float *d = lTpl + i * 192 + lane;
+              float *d = lTpl + (slot0 + c0 + kk) * 192 + lane;
               d[0] = t;
               d[64] = gx;
               d[128] = gy;
@@ -634,12 +653,12 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
               // hand, not wherever a build's scheduling happens to allow it: both register budgets of this kernel
               // (LEAN or not) then produce the same bits
               float sd[6];
-              sd[0] = gx * rl(cx[0], kk);
-              sd[1] = gy * rl(cy[1], kk);
-              sd[2] = __builtin_fmaf(gx, rl(cx[2], kk), gy * rl(cy[2], kk));
-              sd[3] = __builtin_fmaf(gx, rl(cx[3], kk), gy * rl(cy[3], kk));
-              sd[4] = __builtin_fmaf(gx, rl(cx[4], kk), gy * rl(cy[4], kk));
-              sd[5] = __builtin_fmaf(gx, rl(cx[5], kk), gy * rl(cy[5], kk));
+              sd[0] = gx * qz.x;
+              sd[1] = gy * qz.y;
+              sd[2] = __builtin_fmaf(gx, qx.x, gy * qy.x);
+              sd[3] = __builtin_fmaf(gx, qx.y, gy * qy.y);
+              sd[4] = __builtin_fmaf(gx, qx.z, gy * qy.z);
+              sd[5] = __builtin_fmaf(gx, qx.w, gy * qy.w);
               int jk = 0;
 #pragma unroll
               for (int j = 0; j < 6; ++j)
@@ -683,8 +702,6 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
     const __amdgpu_buffer_rsrc_t rcur =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl.cur), 0, 0x7fffffff, 0x00020000);
     const bool single = mycnt <= 64;
-    float *recw = sRecW[wave];
-    const float4 *recw4 = reinterpret_cast<const float4 *>(recw);
     while (sSt.active) {  // workgroup-uniform: read after a barrier, rewritten only between barriers
       float acc[6];
 #pragma unroll
@@ -707,105 +724,85 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
         const float mx = (tx / tz) * lc.fx + lc.cx;
         const float my = (ty / tz) * lc.fy + lc.cy;
         const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
-        const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
+        const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
         const int base_v = ((tp.row0 - 1) * sw + tp.col0 - 1) * 4;  // bytes: the buffer load's scalar offset
-        {
-          float4 *r4 = reinterpret_cast<float4 *>(recw + lane * 8);
-          r4[0] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
-          r4[1] = make_float4(vis ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+        float4 *const recs = lRec + (size_t)(slot0 + c0) * 4;  // this chunk's records
+        if (pv) {
+          recs[lane * 4] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
+          reinterpret_cast<float *>(recs + lane * 4 + 3)[2] = vis ? 1.0f : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T1_MARK(3)  // stage 1
-        // stage 2: one patch per step, software-pipelined
+        // stage 2: kUi patches per step, software-pipelined over whole steps: the slots behind the chunk's last point
+        // are padding (zero record, zero patch -> an exact zero contribution) or the next chunk's, and a lane index past
+        // 63 wraps (v_readlane uses six bits) to some in-plane window, so neither the loop nor the prefetch checks bounds
+        const float *const tpls = lTpl + (size_t)(slot0 + c0) * 192 + lane;
         auto issue = [&](T8Loads<kUi> &L, int k) {
 #pragma unroll
           for (int u = 0; u < kUi; ++u) {
-            const bool ok = k + u < cn;
-            const int kk = ok ? k + u : k;
-            L.k[u] = ok ? kk : -1;
-            const int soff = rl(base_v, kk);
+            const int soff = rl(base_v, k + u);
 #ifdef ICTR_T1_PROF
             if (dbg & 2) {  // ablation: no current-frame loads
               L.cur[u].cd = f32x2_a4{1.0f + lane, 2.0f};
-              L.cur[u].ab = f32x2_a4{3.0f, 4.0f + kk};
+              L.cur[u].ab = f32x2_a4{3.0f, 4.0f + k};
             } else
 #endif
             {
               L.cur[u].cd = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_cd, soff, 0));
               L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_ab, soff, 0));
             }
-            const int i = wave + (c0 + kk) * nwaves;
-#ifdef ICTR_T1_PROF
-            if (dbg & 4) {  // ablation: no template reads
-              L.t[u] = 100.0f + lane;
-              L.gx[u] = 1.0f;
-              L.gy[u] = 2.0f;
-            } else
-#endif
             if constexpr (TL) {
-              const float *tpl = lTpl + i * 192 + lane;
+              const float *tpl = tpls + (k + u) * 192;
               L.t[u] = tpl[0];
               L.gx[u] = tpl[64];
               L.gy[u] = tpl[128];
-            } else {
-              const int o = i * 64 + lane;
+            } else {  // patches from device memory: a padding slot re-reads the chunk's last patch (its record is zero)
+              const int o = (wave + (c0 + min(k + u, cn - 1)) * nwaves) * 64 + lane;
               L.t[u] = gT[o];
               L.gx[u] = gGx[o];
               L.gy[u] = gGy[o];
             }
           }
         };
-        auto reduce = [&](const T8Loads<kUi> &L) {
-          float4 wv[kUi], q0[kUi], q1[kUi], q2[kUi];
-          float vf[kUi];
+        auto reduce = [&](const T8Loads<kUi> &L, int k) {
+          float4 wv[kUi], qx[kUi], qy[kUi], qz[kUi];
 #pragma unroll
           for (int u = 0; u < kUi; ++u) {  // the patches' scalars: broadcast LDS reads, all in flight together
-            const int kk = L.k[u] < 0 ? 0 : L.k[u];
-            const int i = wave + (c0 + kk) * nwaves;
-#ifdef ICTR_T1_PROF
-            if (dbg & 8) {  // ablation: no per-patch scalar reads
-              wv[u] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
-              vf[u] = 1.0f;
-              q0[u] = q1[u] = q2[u] = make_float4(1e-3f, 2e-3f, 1e-3f, 3e-3f);
-              continue;
-            }
-#endif
-            wv[u] = recw4[kk * 2];
-            vf[u] = recw[kk * 8 + 4];
-            q0[u] = lCoef[i * 3 + 0];
-            q1[u] = lCoef[i * 3 + 1];
-            q2[u] = lCoef[i * 3 + 2];
+            const float4 *r4 = recs + (k + u) * 4;
+            wv[u] = r4[0];
+            qx[u] = r4[1];  // cx2 cx3 cx4 cx5
+            qy[u] = r4[2];  // cy2 cy3 cy4 cy5
+            qz[u] = r4[3];  // cx0 cy1 vis -
           }
 #pragma unroll
           for (int u = 0; u < kUi; ++u) {
-            if (L.k[u] < 0) continue;  // wave-uniform
             // utilities.cpp:107 in the reference's operand order, not contracted: ((w0 a + w1 b) + w2 c) + w3 d
             float inew = wv[u].y * L.cur[u].ab.y + wv[u].x * L.cur[u].ab.x + wv[u].w * L.cur[u].cd.y + wv[u].z * L.cur[u].cd.x;
             if constexpr (PN) inew -= wave_sum_dpp(inew) / 64.0f;  // utilities.cpp:111-112
-            const float r = (L.t[u] - inew) * vf[u];  // pdiff (odometer.cpp:381); 0 out of the new view
+            const float r = (L.t[u] - inew) * qz[u].z;  // pdiff (odometer.cpp:381); 0 out of the new view
             {  // the J^T r sums are compared to tolerance only: explicit multiply-adds (see the level setup)
               const float gr = L.gx[u] * r, hr = L.gy[u] * r;
-              acc[0] = __builtin_fmaf(gr, q0[u].x, acc[0]);                                  // sd1 = Gx cx0
-              acc[1] = __builtin_fmaf(hr, q1[u].y, acc[1]);                                  // sd2 = Gy cy1
-              acc[2] = __builtin_fmaf(gr, q0[u].y, __builtin_fmaf(hr, q1[u].z, acc[2]));     // sd3..sd6 = Gx cxk + Gy cyk
-              acc[3] = __builtin_fmaf(gr, q0[u].z, __builtin_fmaf(hr, q1[u].w, acc[3]));     // (odometer.cpp:319-326)
-              acc[4] = __builtin_fmaf(gr, q0[u].w, __builtin_fmaf(hr, q2[u].x, acc[4]));
-              acc[5] = __builtin_fmaf(gr, q1[u].x, __builtin_fmaf(hr, q2[u].y, acc[5]));
+              acc[0] = __builtin_fmaf(gr, qz[u].x, acc[0]);                                  // sd1 = Gx cx0
+              acc[1] = __builtin_fmaf(hr, qz[u].y, acc[1]);                                  // sd2 = Gy cy1
+              acc[2] = __builtin_fmaf(gr, qx[u].x, __builtin_fmaf(hr, qy[u].x, acc[2]));     // sd3..sd6 = Gx cxk + Gy cyk
+              acc[3] = __builtin_fmaf(gr, qx[u].y, __builtin_fmaf(hr, qy[u].y, acc[3]));     // (odometer.cpp:319-326)
+              acc[4] = __builtin_fmaf(gr, qx[u].z, __builtin_fmaf(hr, qy[u].z, acc[4]));
+              acc[5] = __builtin_fmaf(gr, qx[u].w, __builtin_fmaf(hr, qy[u].w, acc[5]));
             }
           }
         };
         T8Loads<kUi> A, B;
         issue(A, 0);
         for (int k = 0; k < cn; k += 2 * kUi) {
-          if (k + kUi < cn) issue(B, k + kUi);
-          reduce(A);
-          if (k + 2 * kUi < cn) issue(A, k + 2 * kUi);
-          if (k + kUi < cn) reduce(B);
+          issue(B, k + kUi);
+          reduce(A, k);
+          issue(A, k + 2 * kUi);
+          reduce(B, k + kUi);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the records are rewritten by the next chunk
+        __builtin_amdgcn_wave_barrier();  // X, Y, Z and the records of the next chunk
       }
       T1_MARK(4)  // stage 2 of wave 0
       T1_REDUCE_STORE(6, acc, sPart[wave])
@@ -846,9 +843,12 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
 
 // ---------------------------------------------------------------- host-side launcher
 // LDS a workgroup needs beyond the static part; tmpl_lds is switched off when the templates do not fit.
-size_t track1_plan(int npts_cap, int n, int p8, int *tmpl_lds) {
-  const size_t recb = (size_t)npts_cap * (p8 ? 48 : 68);  // 8x8: 12 coefficient floats; else 64-byte record + base
-  const size_t tmplb = (size_t)npts_cap * n * 3 * sizeof(float);
+// slots per wave of the 8x8 form: the wave's share of the points, whole pipeline steps of four, two steps of slack
+static int track1_cap_w(int npts_cap, int waves) { return (((npts_cap + waves - 1) / waves + 3) & ~3) + 4; }
+size_t track1_plan(int npts_cap, int n, int p8, int waves, int *tmpl_lds) {
+  const size_t slots = p8 ? (size_t)waves * track1_cap_w(npts_cap, waves) : (size_t)npts_cap;
+  const size_t recb = slots * (p8 ? 64 : 68);  // 8x8: one 64-byte record per slot; else 64-byte record + base
+  const size_t tmplb = slots * n * 3 * sizeof(float);
   const size_t budget = 140 * 1024;  // of the CU's 160 KB; the static arrays (sRecW, partial sums, state) take ~18 KB
   *tmpl_lds = (recb + tmplb <= budget) ? 1 : 0;
   return recb + (*tmpl_lds ? tmplb : 0);
@@ -878,7 +878,7 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
   for (int l = 0; l < 16; ++l) a.lc[l] = cams[l < e.nlev ? l : 0];
   a.npts_cap = (std::max(maxpts, 1) + 3) & ~3;  // keeps the LDS template arrays 16-byte aligned
   a.dbg = 0;
-  a.pad_ = 0;
+  a.cap_w = 0;
   a.st_words = (int)(sizeof(ProbState) / 4);
   a.pl_words = (int)(sizeof(PlaneSet) / 4) * e.nlev;
   a.host_st = host_st;
@@ -894,8 +894,9 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
 #endif
   const bool p8 = e.P == 8 && !e.robust;  // the lean 8x8 form; behaviour-changing options run in the any-size form
   int tl = 0;
-  const size_t lds = track1_plan(a.npts_cap, e.n, p8 ? 1 : 0, &tl);
   waves = std::min(std::max(waves, 1), p8 ? kT8MaxWaves : kT1MaxWaves);
+  const size_t lds = track1_plan(a.npts_cap, e.n, p8 ? 1 : 0, waves, &tl);
+  if (p8) a.cap_w = track1_cap_w(a.npts_cap, waves);
   static size_t g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (p8) {
     // more workgroups than CUs, and two of them fit one CU's LDS: the 128-register build (see k_track1_p8)

@@ -18,7 +18,5 @@ for n in (60, 100, 300):
         eng.SetPose(0, sc["p_a"], pa, pb)
         t0 = time.perf_counter(); eng.track_async(); eng.poses(); ts.append(time.perf_counter() - t0)
     c = eng.read_buffer(0, 9, 8)
-    tm = eng.read_buffer(0, 10, 4)
-    print("   solver cycles: apply", int(tm[0]), "update", int(tm[1]), "exp", int(tm[2]), "rest", int(tm[3]))
     tot = c.sum()
     print(n, "ms", round(np.median(ts) * 1e3, 3), {k: int(v) for k, v in zip(names, c)}, "total cycles", int(tot), flush=True)
