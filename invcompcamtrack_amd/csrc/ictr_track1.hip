@@ -513,8 +513,8 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
   // weights and the visibility flag rewritten by the point's own lane in every iteration's stage 1, the ten non-zero
   // steepest-descent coefficients once per level -- and (TL) the patch [T | Gx | Gy][64]. Stage 2 walks a wave's slots
   // with ONE running address each: four broadcast ds_read_b128 and three ds_read_b32 at immediate offsets per patch, no
-  // index arithmetic. The slots behind a wave's last point stay zero (weights, flag, patches): the patch loop runs in
-  // whole pipeline steps and prefetches past the end without a single bounds check.
+  // index arithmetic. The slot behind a wave's last point stays zero (weights, flag, patch): the patch loop runs in
+  // whole pipeline steps of kUi patches without a per-patch bounds check.
   const int cap_w = a.cap_w;
   float4 *lRec = reinterpret_cast<float4 *>(sDyn);                      // [nwaves * cap_w][4]
   float *lTpl = sDyn + (size_t)nwaves * cap_w * 16;                    // [nwaves * cap_w][T | Gx | Gy][64] when TL
@@ -735,9 +735,9 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         T1_MARK(3)  // stage 1
-        // stage 2: kUi patches per step, software-pipelined over whole steps: the slots behind the chunk's last point
-        // are padding (zero record, zero patch -> an exact zero contribution) or the next chunk's, and a lane index past
-        // 63 wraps (v_readlane uses six bits) to some in-plane window, so neither the loop nor the prefetch checks bounds
+        // stage 2: kUi patches per step, software-pipelined. A step is never split: the slot behind an odd chunk's last
+        // point is padding (zero record, zero patch -> an exact zero contribution; its lane's window is the harmless
+        // in-plane one of stage 1), so no patch checks bounds
         const float *const tpls = lTpl + (size_t)(slot0 + c0) * 192 + lane;
         auto issue = [&](T8Loads<kUi> &L, int k) {
 #pragma unroll
@@ -795,11 +795,11 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
         };
         T8Loads<kUi> A, B;
         issue(A, 0);
-        for (int k = 0; k < cn; k += 2 * kUi) {
-          issue(B, k + kUi);
+        for (int k = 0; k < cn; k += 2 * kUi) {  // step-level guards only (scalar compare + branch per kUi patches)
+          if (k + kUi < cn) issue(B, k + kUi);
           reduce(A, k);
-          issue(A, k + 2 * kUi);
-          reduce(B, k + kUi);
+          if (k + 2 * kUi < cn) issue(A, k + 2 * kUi);
+          if (k + kUi < cn) reduce(B, k + kUi);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // X, Y, Z and the records of the next chunk
@@ -843,8 +843,8 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
 
 // ---------------------------------------------------------------- host-side launcher
 // LDS a workgroup needs beyond the static part; tmpl_lds is switched off when the templates do not fit.
-// slots per wave of the 8x8 form: the wave's share of the points, whole pipeline steps of four, two steps of slack
-static int track1_cap_w(int npts_cap, int waves) { return (((npts_cap + waves - 1) / waves + 3) & ~3) + 4; }
+// slots per wave of the 8x8 form: the wave's share of the points, rounded up to whole pipeline steps of two patches
+static int track1_cap_w(int npts_cap, int waves) { return ((npts_cap + waves - 1) / waves + 1) & ~1; }
 size_t track1_plan(int npts_cap, int n, int p8, int waves, int *tmpl_lds) {
   const size_t slots = p8 ? (size_t)waves * track1_cap_w(npts_cap, waves) : (size_t)npts_cap;
   const size_t recb = slots * (p8 ? 64 : 68);  // 8x8: one 64-byte record per slot; else 64-byte record + base
