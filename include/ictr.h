@@ -192,8 +192,13 @@ int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double 
  *   bit 8 (256)    H accumulated by the setup kernel instead of by the level's first iteration launch
  *   bits 9-11      ablation switches of the 8x8 setup kernel (512 no stores; with bit 12 also 1024 one plane's taps for
  *                  all three, 2048 no taps): WRONG RESULTS, timing only
- *   bit 12 (4096)  three separate reference planes instead of the packed {img,dx,dy,0} texels */
+ *   bit 12 (4096)  three separate reference planes instead of the packed {img,dx,dy,0} texels
+ *   bit 13 (8192)  per-iteration launches whatever the problem size; bit 14 (16384) the one-launch tracker;
+ *   bit 15 (32768) plain launches instead of the hipGraph replay; bit 18 (262144) begin phase as separate operations;
+ *   bit 19 (524288) one workgroup per problem in the one-launch tracker (no teams, see ictr_batch_set_team) */
 int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
+/* one-launch tracker, team form (see ictr_batch_set_team) */
+int ictr_odometer_set_team(ictr_odometer *odo, int target_points, int min_points, int max_points);
 int ictr_odometer_set_robust(ictr_odometer *odo, int flags, float huber_k); /* see ictr_batch_set_robust */
 
 /* ------------------------------------------------------------------ batched engine (B independent problems) */
@@ -221,6 +226,13 @@ int ictr_batch_get_poses(ictr_batch *b, double *p_out);
 int ictr_batch_get_iterations(ictr_batch *b, int *iters);
 int ictr_batch_get2dpoints(ictr_batch *b, int64_t problem, float *host_out /* 2*M */);
 int ictr_batch_set_variant(ictr_batch *b, int variant); /* bits: see ictr_odometer_set_variant */
+/* One-launch tracker, team form: a problem of min_points < nopoints <= max_points 8x8 patches is shared by several
+ * workgroups (at most 64) that all-gather their partial sums inside the launch. target_points > 0: ceil(nopoints /
+ * target_points) workgroups, a function of the problem's point count only; 0: automatic (shares of 40-128 points for a
+ * lone problem, a batch sized so that its workgroups are resident together; depends on the batch size too); < 0: never.
+ * Defaults 0 / 128 / 8192 (environment: ICTR_TEAM_TARGET / ICTR_TEAM_MINPTS / ICTR_TEAM_MAXPTS); tests use small
+ * targets to exercise many, ragged and empty shares. Results equal the other launch forms up to summation order. */
+int ictr_batch_set_team(ictr_batch *b, int target_points, int min_points, int max_points);
 /* Behaviour-changing robustness options, all OFF by default (the default reproduces the reference, quirks included).
  * flags: ICTR_ROBUST_CLEAN  points outside the reference view at a level contribute nothing (the reference reuses
  *                           their stale patches and sd coefficients, odometer.cpp:304);
@@ -253,6 +265,9 @@ int ictr_batch_get_setup_intervals(ictr_batch *b, float *start_ms, float *end_ms
 /* which launch form the last tracking used: 0 = per-iteration launches (large problems), 1 = the one-launch tracker
  * (whole odometer.cpp:257-426 loop in one kernel, one workgroup per problem; chosen for small problems) */
 int ictr_batch_last_path(const ictr_batch *b);
+/* workgroups per problem of that launch when it was the one-launch tracker (1 otherwise): problems of a few hundred to a
+ * few thousand 8x8 patches are shared by a team of workgroups that all-gather their partial sums inside the launch */
+int ictr_batch_last_team(const ictr_batch *b);
 
 /* ---- distributed (points sharded over ranks): split phases so the caller can all-reduce ----
  * The normal-equation block lives in a caller-visible device buffer: per problem 21 floats of H

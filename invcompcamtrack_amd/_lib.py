@@ -101,6 +101,7 @@ SIGNATURES = {
     "ictr_odometer_read_buffer": (C.c_int, [VP, C.c_int, FP, I64]),
     "ictr_odometer_get_norm": (C.c_int, [VP, DP, DP]),
     "ictr_odometer_set_variant": (C.c_int, [VP, C.c_int]),
+    "ictr_odometer_set_team": (C.c_int, [VP, C.c_int, C.c_int, C.c_int]),
     "ictr_odometer_set_robust": (C.c_int, [VP, C.c_int, C.c_float]),
     "ictr_batch_create": (C.c_int, [C.POINTER(VP), VP, C.POINTER(OptParam), I64]),
     "ictr_batch_destroy": (None, [VP]),
@@ -115,6 +116,7 @@ SIGNATURES = {
     "ictr_batch_get_iterations": (C.c_int, [VP, IP]),
     "ictr_batch_get2dpoints": (C.c_int, [VP, I64, FP]),
     "ictr_batch_set_variant": (C.c_int, [VP, C.c_int]),
+    "ictr_batch_set_team": (C.c_int, [VP, C.c_int, C.c_int, C.c_int]),
     "ictr_batch_set_robust": (C.c_int, [VP, C.c_int, C.c_float]),
     "ictr_batch_read_buffer": (C.c_int, [VP, I64, C.c_int, FP, I64]),
     "ictr_batch_set_timing": (C.c_int, [VP, C.c_int]),
@@ -122,6 +124,7 @@ SIGNATURES = {
     "ictr_batch_get_kernel_times": (C.c_int, [VP, FP]),
     "ictr_batch_get_first_iter_times": (C.c_int, [VP, FP]),
     "ictr_batch_last_path": (C.c_int, [VP]),
+    "ictr_batch_last_team": (C.c_int, [VP]),
     "ictr_timebase_mark": (C.c_int, []),
     "ictr_batch_get_kernel_intervals": (C.c_int, [VP, FP, FP]),
     "ictr_batch_get_setup_intervals": (C.c_int, [VP, FP, FP]),

@@ -49,6 +49,15 @@ struct ProbState {
   int pad_;
 };
 
+// team form of the one-launch tracker (ictr_track1.hip, "Teams"): several workgroups per problem
+struct T1Team {
+  int team, q;               // workgroups per problem, points per workgroup
+  unsigned tag0;             // launch epoch << 12
+  unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
+  unsigned long long *mail;  // [B][2][team][32] granules
+  int *err;                  // sticky time-out flag (pinned host memory as the device sees it)
+};
+
 struct DevTrace {
   ictr_trace_rec *rec;
   int *count;

@@ -38,7 +38,11 @@ void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, i
 void launch_iter_tail(const EngineDev &, int, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
-hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t);
+hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t,
+                         const T1Team *);
+int track1_team_q(int, int);
+int track1_team_size(int, int);
+size_t track1_team_mail_bytes(int, int);
 size_t track1_blob_bytes(void);
 size_t track1_plan(int, int, int, int, int *);
 }  // namespace ictr
@@ -754,9 +758,23 @@ struct ictr_batch {
   ProbState *h_st_pin = nullptr;
   ProbState *d_st_mirror = nullptr;  // h_st_pin as the device sees it (the one-launch tracker stores final states there)
   char *h_up_pin = nullptr;  // pinned staging of the per-tracking uploads (states + plane table): truly asynchronous
+  // team form of the one-launch tracker (several workgroups per problem, ictr_track1.hip "Teams")
+  unsigned long long *d_team_mail = nullptr;  // granule mailboxes [B][2][team][32]; allocated on first use
+  size_t team_mail_bytes = 0;
+  unsigned team_epoch = 0;    // tags of a launch: epoch << 12 | exchange number
+  int last_team = 1;          // workgroups per problem of the last one-launch tracking
+  int team_target = 0;        // points per workgroup aimed at (0: automatic, < 0: no teams); ictr_batch_set_team
+  int team_lo = 128, team_hi = 8192;  // problem sizes (points) served by teams: lo < maxpts <= hi
+  int *h_team_err = nullptr;  // pinned: an exchange of some launch timed out (sticky)
+  int *d_team_err = nullptr;  // ... as the device sees it
   hipEvent_t done_ev = nullptr, up_ev = nullptr;
   bool done_valid = false, up_pending = false;
 };
+
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
 
 static void batch_free(ictr_batch *b) {
   if (!b) return;
@@ -768,6 +786,8 @@ static void batch_free(ictr_batch *b) {
   if (b->up_ev) (void)hipEventDestroy(b->up_ev);
   if (b->h_st_pin) (void)hipHostFree(b->h_st_pin);
   if (b->h_up_pin) (void)hipHostFree(b->h_up_pin);
+  if (b->h_team_err) (void)hipHostFree(b->h_team_err);
+  if (b->d_team_mail) (void)hipFree(b->d_team_mail);
   b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
@@ -843,6 +863,9 @@ extern "C" int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ic
   b->P = op->psz;
   b->n = op->novals;
   b->nlev = op->lv_f + 1;
+  b->team_target = env_int("ICTR_TEAM_TARGET", 0);  // 0: automatic (team_points), < 0: never
+  b->team_lo = env_int("ICTR_TEAM_MINPTS", 128);    // up to here ONE workgroup per problem is as fast (tools/team_sweep.py)
+  b->team_hi = env_int("ICTR_TEAM_MAXPTS", 8192);   // beyond: the per-iteration kernels
   const size_t B = b->B, M = b->M, n = b->n, L = b->nlev;
   const int ppw = (b->n <= 64 && 64 % b->n == 0) ? 64 / b->n : 1;
   const int64_t groups = (b->M + ppw - 1) / ppw;
@@ -906,6 +929,15 @@ extern "C" int ictr_batch_set_robust(ictr_batch *b, int flags, float huber_k) {
     return fail(ICTR_ERR_INVALID, "set_robust: the Huber threshold must be positive");
   b->robust = flags;
   b->huber_k = huber_k;
+  return ICTR_OK;
+}
+extern "C" int ictr_batch_set_team(ictr_batch *b, int target_points, int min_points, int max_points) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (min_points < 0 || max_points < min_points)
+    return fail(ICTR_ERR_INVALID, "set_team: need 0 <= min_points <= max_points");
+  b->team_target = target_points;
+  b->team_lo = min_points;
+  b->team_hi = max_points;
   return ICTR_OK;
 }
 extern "C" int ictr_batch_set_variant(ictr_batch *b, int variant) {
@@ -1163,10 +1195,50 @@ extern "C" int ictr_batch_iter_finish(ictr_batch *b, int level) {
 // one workgroup per problem (ictr_track1.hip): below ~1000 points the per-iteration launch pairs are pure
 // dependent-launch latency. Not for sharded batches (they need collectives between phases) and not when per-launch
 // event timing is on. Variant bit 13 forces the per-iteration launches, bit 14 the one-launch tracker.
+// Team form ("Teams", ictr_track1.hip): 8x8 problems above the one-workgroup range are shared by several workgroups
+// that all-gather their partial sums through a device mailbox -- still one launch per tracking. Variant bit 19
+// (524288) switches the form off (A/B).
+// Points per workgroup aimed at for the current tracking; 0 = no teams. Explicit (ictr_batch_set_team, ICTR_TEAM_TARGET):
+// a function of the problem size alone. Automatic (measured, tools/team_sweep.py, profiles/r02_notes.md): a lone problem
+// is fastest in shares of 40 points (five patches per wave; the all-gather of up to 64 shares is one round trip);
+// a batch wants all its workgroups resident at once, one per CU, down to the largest share whose patches fit the LDS
+// (160 points); when even that does not fit the chip, problems of up to 384 points go back to one workgroup each
+// (two per CU in the 128-register build), larger ones take the smallest team.
+static int team_points(const ictr_batch *b) {
+  if (b->team_target != 0) return b->team_target >= 8 ? b->team_target : 0;
+  const int n = b->maxpts;
+  const int upper = std::min(64, (n + 39) / 40), lower = (n + 159) / 160;
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+      v = 256;
+    return v;
+  }();
+  const int fit = std::max(1, n_cu / std::max(1, b->B));
+  if (fit < lower && n <= 384) return 0;
+  const int team = std::min(upper, std::max(lower, fit));
+  return team < 2 ? 0 : (n + team - 1) / team;
+}
+// workgroups per problem of the current tracking, 1 = not the team form
+static int track1_team(const ictr_batch *b) {
+  static const int maxwg = env_int("ICTR_TEAM_MAXWG", 4096);   // workgroups of one launch
+  const int v = engine_variant(b);
+  if ((v & (1 << 19)) || b->P != 8 || b->robust) return 1;
+  if (b->maxpts <= b->team_lo || b->maxpts > b->team_hi) return 1;
+  if ((int64_t)b->nlev * (1 + std::max(0, b->op->maxiter)) >= 4000) return 1;  // exchange number: 12 bits of the tag
+  const int target = team_points(b);
+  if (target < 1) return 1;
+  const int team = track1_team_size(b->maxpts, target);
+  if (team < 2 || (int64_t)team * b->B > maxwg) return 1;
+  return team;
+}
 static bool use_track1(const ictr_batch *b) {
   const int v = engine_variant(b);
   if (b->sharded || b->timing || (v & 8192)) return false;
-  if (b->maxpts < 1 || (size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS
+  if (b->maxpts < 1) return false;
+  if (track1_team(b) > 1) return true;
+  if ((size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS
   if (v & 16384) return true;
   // Measured (tools/latency.py, r02): one problem costs 0.17 ms + 1.9 us per 8x8 patch in one launch against a flat
   // 0.52 ms of dependent launches -> cross-over near 190 points; a batch of independent problems (run_track_nposes:
@@ -1188,6 +1260,55 @@ static int track1_waves(const ictr_batch *b) {
   }();
   (void)b;
   return forced > 0 ? forced : 8;
+}
+
+// mailbox, tag epoch and error flag of the next team launch (tm->team == 1: not a team launch, nothing allocated)
+static int team_prepare(ictr_batch *b, T1Team *tm) {
+  memset(tm, 0, sizeof(*tm));
+  tm->team = track1_team(b);
+  if (tm->team < 2) {
+    tm->team = 1;
+    return ICTR_OK;
+  }
+  tm->q = track1_team_q(b->maxpts, team_points(b));
+  const size_t need = track1_team_mail_bytes(b->B, tm->team);
+  if (need > b->team_mail_bytes) {
+    if (b->d_team_mail) {
+      HIPCHK(hipStreamSynchronize(b->stream));  // an earlier launch may still be polling the old mailbox
+      HIPCHK(hipFree(b->d_team_mail));
+      b->d_team_mail = nullptr;
+      b->team_mail_bytes = 0;
+    }
+    // granules are written and polled with agent-scope accesses; uncached device memory keeps them out of the L2s
+    hipError_t e = hipExtMallocWithFlags((void **)&b->d_team_mail, need, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipMalloc((void **)&b->d_team_mail, need);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_team_mail, 0, need, b->stream);  // tag 0: "nothing yet"
+    if (e != hipSuccess) return fail(ICTR_ERR_HIP, "team mailbox allocation failed: %s", hipGetErrorString(e));
+    b->team_mail_bytes = need;
+    b->team_epoch = 0;
+  }
+  if (!b->h_team_err) {
+    HIPCHK(hipHostMalloc((void **)&b->h_team_err, sizeof(int), hipHostMallocDefault));
+    *b->h_team_err = 0;
+    HIPCHK(hipHostGetDevicePointer((void **)&b->d_team_err, b->h_team_err, 0));
+  }
+  b->team_epoch += 1;
+  if (b->team_epoch >= (1u << 20)) {  // the epoch field wrapped: forget every old tag
+    HIPCHK(hipMemsetAsync(b->d_team_mail, 0, b->team_mail_bytes, b->stream));
+    b->team_epoch = 1;
+  }
+  static const double limit_s = [] {
+    const char *s = getenv("ICTR_TEAM_TIMEOUT_S");
+    return s ? std::max(0.001, atof(s)) : 2.0;
+  }();
+  tm->tag0 = b->team_epoch << 12;
+  tm->limit = (unsigned long long)(limit_s * 1e8);
+  tm->mail = b->d_team_mail;
+  tm->err = b->d_team_err;
+  return ICTR_OK;
 }
 
 // Launch-bound sizes (a few hundred to a few thousand points: every kernel of the per-iteration form runs 2-5 us)
@@ -1280,7 +1401,10 @@ static int enqueue_levels(ictr_batch *b) {
   if (use_track1(b)) {
     LevelCam cams[16];
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
-    HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream));
+    T1Team tm;
+    if (int rc = team_prepare(b, &tm)) return rc;
+    HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream, tm.team > 1 ? &tm : nullptr));
+    b->last_team = tm.team;
     b->last_path = 1;
     return ICTR_OK;
   }
@@ -1323,7 +1447,11 @@ static int track_enqueue(ictr_batch *b) {
     memcpy(blob + nst, b->h_planes.data(), npl);
     LevelCam cams[16];
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
-    HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream));
+    T1Team tm;
+    if (int rc = team_prepare(b, &tm)) return rc;
+    HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream,
+                         tm.team > 1 ? &tm : nullptr));
+    b->last_team = tm.team;
     b->last_path = 3;
     mirrored = true;
   } else if (int rc = enqueue_levels(b)) {
@@ -1348,6 +1476,9 @@ static int batch_wait(ictr_batch *b) {
     HIPCHK(hipEventSynchronize(b->done_ev));
   else
     HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->h_team_err && *(volatile int *)b->h_team_err)
+    return fail(ICTR_ERR_HIP, "one-launch tracker, team form: a workgroup waited in vain for its team's partial sums "
+                              "(time-out); the results of this batch are invalid");
   return ICTR_OK;
 }
 
@@ -1447,6 +1578,9 @@ extern "C" int ictr_batch_get_setup_intervals(ictr_batch *b, float *start_ms, fl
   return ICTR_OK;
 }
 extern "C" int ictr_batch_last_path(const ictr_batch *b) { return b ? b->last_path : -1; }
+extern "C" int ictr_batch_last_team(const ictr_batch *b) {
+  return b ? ((b->last_path == 1 || b->last_path == 3) ? b->last_team : 1) : -1;
+}
 extern "C" int ictr_batch_set_reduction_buffer(ictr_batch *b, float *dev_ptr) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   b->d_red = dev_ptr ? dev_ptr : b->d_red_own;
@@ -1524,6 +1658,10 @@ extern "C" int ictr_odometer_set_stream(ictr_odometer *o, void *s) {
 extern "C" int ictr_odometer_set_robust(ictr_odometer *o, int flags, float huber_k) {
   if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
   return ictr_batch_set_robust(o->b, flags, huber_k);
+}
+extern "C" int ictr_odometer_set_team(ictr_odometer *o, int target_points, int min_points, int max_points) {
+  if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");
+  return ictr_batch_set_team(o->b, target_points, min_points, max_points);
 }
 extern "C" int ictr_odometer_set_variant(ictr_odometer *o, int v) {
   if (!o) return fail(ICTR_ERR_INVALID, "odometer is NULL");

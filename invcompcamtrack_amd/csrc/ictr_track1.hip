@@ -44,6 +44,8 @@ constexpr int kT8MaxWaves = 8;  // 8x8 form
 // table, byte for byte what ictr_batch_begin would copy), workgroup b stores its problem's part to device memory for
 // later readers, runs step 3 (k_project_ref's arithmetic) for its own points, and at the end writes the final state
 // straight into the host's pinned mirror as well: one launch and one event per tracking.
+constexpr int kTeamSlot = 32;     // granules per workgroup and exchange (21 of H or 6 of b)
+constexpr int kTeamMax = 64;      // workgroups per problem
 constexpr int kT1BlobWords = 704;  // 2816 B: 4 problems x (ProbState 496 B + 5 levels x 40 B)
 struct T1Args {
   LevelCam lc[16];
@@ -53,6 +55,12 @@ struct T1Args {
   int st_words, pl_words;  // dwords per problem of the blob's two sections
   int cap_w;               // 8x8 form: LDS slots per wave (>= its points, rounded up to whole pipeline steps + prefetch)
   ProbState *host_st;      // pinned host mirror of the final states [B], or nullptr
+  // team form (k_track1_p8<..., TEAM>): `team` workgroups share one problem, see "Teams" below
+  int team, team_q;                // workgroups per problem; points per workgroup (the last one may own fewer)
+  unsigned team_tag0;              // launch epoch << 12: granule tags of this launch are team_tag0 + exchange number
+  unsigned long long team_limit;   // polling limit in wall_clock64 ticks (100 MHz)
+  unsigned long long *team_mail;   // [B][2][team][kTeamSlot] granules {float bits, tag}
+  int *team_err;                   // sticky flag (pinned host memory): an exchange timed out
   __attribute__((aligned(8))) unsigned blob[kT1BlobWords];  // [ProbState x B][PlaneSet x B x nlev]
 };
 
@@ -88,21 +96,26 @@ __device__ __forceinline__ PlaneSet t1_planes(const EngineDev &e, const T1Args &
 }
 // ictr_batch_begin's device part for problem b: state + plane table to device memory, then step 3 for every level
 // (pose.cpp:400-488 at lv_f, pose.cpp:307-397 below it; the camera-frame point is level independent)
-__device__ __forceinline__ void t1_fused_begin(const EngineDev &e, const T1Args &a, int b, int tid, int nthr) {
+// (team form: workgroup `part` of `team` projects its own points [part q, part q + q) only; part 0 stores the tables)
+__device__ __forceinline__ void t1_fused_begin(const EngineDev &e, const T1Args &a, int b, int tid, int nthr,
+                                               int part = 0, int q = 0x7fffffff) {
   const unsigned *bs = a.blob + (size_t)b * a.st_words;
-  unsigned *ds = reinterpret_cast<unsigned *>(e.st + b);
-  for (int i = tid; i < a.st_words; i += nthr) ds[i] = bs[i];
-  const unsigned *bp = a.blob + (size_t)e.B * a.st_words + (size_t)b * a.pl_words;
-  unsigned *dp = reinterpret_cast<unsigned *>(const_cast<PlaneSet *>(e.planes) + (size_t)b * e.nlev);
-  for (int i = tid; i < a.pl_words; i += nthr) dp[i] = bp[i];
+  if (part == 0) {
+    unsigned *ds = reinterpret_cast<unsigned *>(e.st + b);
+    for (int i = tid; i < a.st_words; i += nthr) ds[i] = bs[i];
+    const unsigned *bp = a.blob + (size_t)e.B * a.st_words + (size_t)b * a.pl_words;
+    unsigned *dp = reinterpret_cast<unsigned *>(const_cast<PlaneSet *>(e.planes) + (size_t)b * e.nlev);
+    for (int i = tid; i < a.pl_words; i += nthr) dp[i] = bp[i];
+  }
   const ProbState *st = reinterpret_cast<const ProbState *>(bs);
-  const int npts = st->npts;
+  const int lo = (int)min((long long)part * q, (long long)st->npts);
+  const int npts = (int)min((long long)st->npts, (long long)lo + q);
   float G[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) G[k] = st->G[k];
   const float *p3 = e.pt3d + (size_t)b * 3 * e.M;
   float *p3r = e.pt3d_ref + (size_t)b * 3 * e.M;
-  for (int i = tid; i < npts; i += nthr) {
+  for (int i = lo + tid; i < npts; i += nthr) {
     const float X = p3[i], Y = p3[i + e.M], Z = p3[i + 2 * e.M];
     const float tx = G[0] * X + G[1] * Y + G[2] * Z + G[3];
     const float ty = G[4] * X + G[5] * Y + G[6] * Z + G[7];
@@ -444,6 +457,96 @@ __global__ __launch_bounds__(64 * kT1MaxWaves) void k_track1(EngineDev e, T1Args
 #endif
 }
 
+// ---------------------------------------------------------------- Teams: several workgroups per problem
+// Between the one-workgroup range (<= ~200 points) and the sizes where the per-iteration kernels carry real work the
+// tracker is a chain of ~111 dependent 2-us launches (0.5 ms whatever the point count), and a batch of mid-size
+// problems (run_track_nposes with a few hundred points) keeps one CU busy per problem for 10 us per iteration. In the
+// team form `team` workgroups (consecutive block ids) share one problem: workgroup `part` owns the points
+// [part q, part q + q) for the whole tracking -- its own share of patches, records and partial sums, nothing of it is
+// ever read by another workgroup -- and the only exchange is the one the multi-GPU form has: the 21
+// sums of H once per level and the 6 of b once per iteration, all-gathered through a mailbox in device memory; every
+// workgroup then adds the parts in part order and runs the same solver turn on the same bits, so the redundant poses and
+// loop conditions stay in lockstep without a second hop. A value travels as ONE naturally aligned 8-byte granule
+// {float bits, tag} written by one agent-scope store and polled on its tag (ictr_p2p.hip's protocol; no flag, no fence:
+// MI355X_MICROARCH.md "Valid forms", R2); tags = launch epoch << 12 | exchange number, so nothing is cleared between
+// launches; slots are double-buffered by the exchange number's parity (a workgroup can be at most one exchange ahead of
+// its slowest peer, which still owes it that exchange's granules). Polling is bounded by a wall-clock limit: on a
+// time-out the workgroup raises a sticky flag in pinned host memory and stops waiting for good, so every wave reaches
+// the end of the kernel (the host reports the tracking as failed). Progress needs the team's workgroups resident
+// together: they are consecutive block ids of an in-order dispatch, so the lowest unfinished problem always holds its CUs.
+struct TeamCtx {
+  unsigned long long *mail;  // this problem's mailbox [2][team][kTeamSlot]
+  int team, part;
+  unsigned tag0, seq;        // seq: exchanges done so far in this launch
+  unsigned long long limit;
+  int *err;
+  int dead;                  // a poll timed out: never wait again
+};
+__device__ __forceinline__ double lane_gather64(double v, int src_lane) {
+  const int lo = lane_gather(__double2loint(v), src_lane), hi = lane_gather(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+// Wave 0 only. Lane k < N passes the workgroup's k-th value; lanes k < N (of the first LPP) receive the team's total in
+// f64. LPP = lanes per part in a polling sweep (a power of two >= N): lane (rr, k) reads value k of the parts rr,
+// rr + 64/LPP, ... -- eight granule loads in flight per lane, so a team of up to 8 * 64/LPP parts costs ONE round trip
+// -- and adds them in that order; the 64/LPP lane groups are then added in group order. The same fixed order in every
+// workgroup: the same bits everywhere.
+template <int N, int LPP>
+__device__ __forceinline__ double team_allsum(TeamCtx &c, float v, int lane) {
+  c.seq += 1;
+  const unsigned tag = c.tag0 + c.seq;
+  unsigned long long *slot = c.mail + (size_t)(c.seq & 1u) * c.team * kTeamSlot;
+  if (lane < N)
+    __hip_atomic_store(slot + c.part * kTeamSlot + lane,
+                       ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  constexpr int PPP = 64 / LPP;  // parts per sweep
+  constexpr int CH = 8;          // sweeps in flight
+  const int k = lane & (LPP - 1), rr = lane / LPP;
+  const unsigned long long empty = (unsigned long long)tag << 32;  // "arrived, value +0": lanes without a granule
+  double acc = 0.0;
+  for (int r0 = 0; r0 < c.team; r0 += CH * PPP) {
+    unsigned long long g[CH];
+    const unsigned long long *src[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int r = r0 + u * PPP + rr;
+      const bool mine = k < N && r < c.team;
+      src[u] = slot + (size_t)(mine ? r : 0) * kTeamSlot + (mine ? k : 0);
+      g[u] = empty;
+      if (mine) g[u] = __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!c.dead) {
+      bool started = false;
+      unsigned long long t0 = 0;
+      for (;;) {
+        bool miss = false;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) miss |= (unsigned)(g[u] >> 32) != tag;
+        if (__builtin_amdgcn_ballot_w64(miss) == 0) break;  // wave-uniform
+        if (!started) {
+          t0 = wall_clock64();
+          started = true;
+        } else if (wall_clock64() - t0 > c.limit) {  // a peer never arrived: flag it, never wait again
+          if (lane == 0) __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          c.dead = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if ((unsigned)(g[u] >> 32) != tag) g[u] = __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) acc += (double)__builtin_bit_cast(float, (unsigned)(g[u] & 0xffffffffu));
+  }
+  double tot = acc;
+#pragma unroll
+  for (int j = 1; j < PPP; ++j) tot += lane_gather64(acc, j * LPP + k);  // (meaningful in the lanes of group 0)
+  return tot;
+}
+
 // ================================================================ 8x8 patches: the lean form
 // A wave owns the points wave, wave + nwaves, ... for the whole tracking, one POINT per lane in "stage 1" (chunks of
 // 64) and one PATCH per step in "stage 2" (lane == pixel). What stage 1 computes for a point (bilinear weights,
@@ -492,7 +595,8 @@ __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readla
 // ~30 spilled registers. A batch of more problems than the chip has CUs runs 20 % faster this way (500 x 60 points:
 // 0.64 -> 0.50 ms); a batch that leaves CUs idle anyway is 5 % faster with the 206-register build (LEAN = false).
 // Same operations in the same order: the two builds give the same bits.
-template <bool TL, bool PN, bool LEAN>
+// TEAM: a.team workgroups per problem ("Teams" above); false: one workgroup per problem, no exchange code at all.
+template <bool TL, bool PN, bool LEAN, bool TEAM>
 __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(EngineDev e, T1Args a) {
   extern __shared__ __attribute__((aligned(16))) float sDyn[];
   __shared__ float sPart[kT8MaxWaves][kPartHStride];  // per-wave partial sums (21 of H, or 6 of b)
@@ -502,7 +606,9 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
   // the per-iteration tails (k_level_tail / k_iter_tail), which keep the state in device memory.
   __shared__ ProbState sSt;
 
-  const int b = blockIdx.x;
+  const int team = TEAM ? a.team : 1;
+  const int b = TEAM ? (int)blockIdx.x / team : (int)blockIdx.x;
+  const int part = TEAM ? (int)blockIdx.x - b * team : 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -520,9 +626,29 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
   float *lTpl = sDyn + (size_t)nwaves * cap_w * 16;                    // [nwaves * cap_w][T | Gx | Gy][64] when TL
   const int slot0 = wave * cap_w;
 
-  if (a.fused_begin) t1_fused_begin(e, a, b, tid, blockDim.x);
+  if (a.fused_begin) {
+    if constexpr (TEAM)
+      t1_fused_begin(e, a, b, tid, blockDim.x, part, a.team_q);
+    else
+      t1_fused_begin(e, a, b, tid, blockDim.x);
+  }
   const ProbState &gst = *t1_initial_state(e, a, b);
-  const int npts = t1_uni(gst.npts);
+  // this workgroup's points: [lo, lo + npts) of the problem's (TEAM; else all of them). Every per-point array below is
+  // addressed relative to lo.
+  const int npts_all = t1_uni(gst.npts);
+  const int lo = TEAM ? min(part * a.team_q, npts_all) : 0;
+  const int npts = TEAM ? min(a.team_q, npts_all - lo) : npts_all;
+  TeamCtx tc;
+  if constexpr (TEAM) {
+    tc.mail = a.team_mail + (size_t)b * 2 * team * kTeamSlot;
+    tc.team = team;
+    tc.part = part;
+    tc.tag0 = a.team_tag0;
+    tc.seq = 0;
+    tc.limit = a.team_limit;
+    tc.err = a.team_err;
+    tc.dead = 0;
+  }
   SolveOpts sopt = solve_opts(e);
   sopt.robust = 0;  // the host routes every behaviour-changing option to the any-size form: no compose / log code here
   {
@@ -536,12 +662,12 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
     __syncthreads();
   }
 
-  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M;
-  const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M;
-  float *gT = e.T + (size_t)b * M * 64;
-  float *gGx = e.Gx + (size_t)b * M * 64;
-  float *gGy = e.Gy + (size_t)b * M * 64;
-  float *coefb = e.coef + (size_t)b * M * kCoefStride;
+  const float *__restrict__ p3 = e.pt3d + (size_t)b * 3 * M + lo;
+  const float *__restrict__ p3r = e.pt3d_ref + (size_t)b * 3 * M + lo;
+  float *gT = e.T + ((size_t)b * M + lo) * 64;
+  float *gGx = e.Gx + ((size_t)b * M + lo) * 64;
+  float *gGy = e.Gy + ((size_t)b * M + lo) * 64;
+  float *coefb = e.coef + ((size_t)b * M + lo) * kCoefStride;
   const int mycnt = wave < npts ? (npts - wave + nwaves - 1) / nwaves : 0;  // points wave, wave + nwaves, ...
   float X1 = 0.0f, Y1 = 0.0f, Z1 = 1.0f;  // the lane's point when the wave has a single chunk
   if (mycnt > 0 && mycnt <= 64) {
@@ -568,7 +694,7 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
 #pragma unroll
       for (int j = 0; j < kHUnique; ++j) acc[j] = 0.0f;
       gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
-      const float *pt2d = e.pt2d + ((size_t)b * e.nlev + sl) * 2 * M;
+      const float *pt2d = e.pt2d + ((size_t)b * e.nlev + sl) * 2 * M + lo;
       for (int c0 = 0; c0 < mycnt; c0 += 64) {
         const int cn = min(64, mycnt - c0);
         // stage A: lane k <-> point i = wave + (c0 + k) nwaves
@@ -688,8 +814,10 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
       const int r = lane / 6, c = lane - 6 * r;
       const int lo = r < c ? r : c, hi = r < c ? c : r;
       const int j = lane < 36 ? lo * 6 - lo * (lo - 1) / 2 + (hi - lo) : 0;
+      float hv = (float)hs;
+      if constexpr (TEAM) hv = (float)team_allsum<kHUnique, 32>(tc, hv, lane);
       WaveSolver S;  // wave 0 is the solver (ictr_devfn.h)
-      ws_factor(S, lane_gather((float)hs, j), lane);
+      ws_factor(S, lane_gather(hv, j), lane);
       ws_store_factor(S, sSt, lane);
       if (lane == 0) level_reset(sSt, e);  // odometer.cpp:341-346
     }
@@ -812,11 +940,21 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
         double bs = 0.0;
         if (lane < 6)
           for (int w = 0; w < nwaves; ++w) bs += (double)sPart[w][lane];
+        float bv = (float)bs;
+        if constexpr (TEAM) {
+          // b is a sum of signed terms: a share's partial can be much larger than the total, so it travels as a
+          // (hi, lo) pair of floats (lanes 0-5 / 6-11) and the team's total is rounded ONCE -- the sum of all waves'
+          // partials in f64, as accurate as a single workgroup's
+          const float lo = (float)(bs - (double)bv);
+          const float pv = lane < 6 ? bv : lane_gather(lo, lane - 6);
+          const double t = team_allsum<12, 16>(tc, pv, lane);
+          bv = (float)(t + lane_gather64(t, lane + 6));
+        }
         WaveSolver S;
         float G[12];
         ws_load_state(S, sSt, lane, G);
         ws_load_factor(S, sSt, lane);
-        ws_iterate(S, (float)bs, sopt, sl, b, lane, G);
+        ws_iterate(S, bv, sopt, sl, TEAM ? b + part : b, lane, G);  // (trace: problem 0's part 0 only)
         ws_store_state(S, sSt, lane, G);
       }
       T1_MARK(6)  // final sum + solve + update
@@ -829,7 +967,7 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
     for (int k = 0; k < 8; ++k) e.partH[(size_t)b * 8 + k] = (float)tp_[k];
   }
 #endif
-  if (wave == 0) {  // final state back to the problem's record, and straight to the host's pinned mirror if there is one
+  if (wave == 0 && part == 0) {  // final state back to the problem's record, and straight to the host's pinned mirror
     const unsigned *src = reinterpret_cast<const unsigned *>(&sSt);
     unsigned *dst = reinterpret_cast<unsigned *>(e.st + b);
     unsigned *hst = reinterpret_cast<unsigned *>(a.host_st ? a.host_st + b : nullptr);
@@ -856,7 +994,7 @@ size_t track1_plan(int npts_cap, int n, int p8, int waves, int *tmpl_lds) {
 
 template <typename K>
 static hipError_t launch_t1(K kernel, size_t *granted, const EngineDev &e, const T1Args &a, int waves, size_t lds,
-                            hipStream_t s) {
+                            hipStream_t s, int team = 1) {
   if (lds > *granted) {  // dynamic LDS above 64 KB must be granted per function
     const size_t want = 141 * 1024;
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -864,18 +1002,43 @@ static hipError_t launch_t1(K kernel, size_t *granted, const EngineDev &e, const
     if (rc != hipSuccess) return rc;
     *granted = want;
   }
-  hipLaunchKernelGGL(kernel, dim3(e.B), dim3(64 * waves), lds, s, e, a);
+  hipLaunchKernelGGL(kernel, dim3(e.B * team), dim3(64 * waves), lds, s, e, a);
   return hipGetLastError();
 }
 
 // bytes of initial state + plane table a launch can carry in its arguments (fused begin, see T1Args)
 size_t track1_blob_bytes(void) { return sizeof(unsigned) * kT1BlobWords; }
 
-// blob (may be NULL): [ProbState x B][PlaneSet x B x nlev] for the fused begin; host_st (may be NULL): pinned mirror
+// Points per workgroup of the team form for a problem of `maxpts` points, and with it the team size -- a function of
+// the point count alone, so a problem's sums (and bits) do not depend on what else shares its launch.
+int track1_team_q(int maxpts, int target) {
+  const int team = std::min(kTeamMax, std::max(1, (maxpts + target - 1) / target));
+  return ((maxpts + team - 1) / team + 7) & ~7;  // whole rows of eight waves
+}
+int track1_team_size(int maxpts, int target) {
+  const int q = track1_team_q(maxpts, target);
+  return std::max(1, (maxpts + q - 1) / q);
+}
+size_t track1_team_mail_bytes(int B, int team) { return sizeof(unsigned long long) * (size_t)B * 2 * team * kTeamSlot; }
+
+// blob (may be NULL): [ProbState x B][PlaneSet x B x nlev] for the fused begin; host_st (may be NULL): pinned mirror;
+// tm (may be NULL): team form -- tm->team workgroups of tm->q points per problem, mailbox, tag epoch, error flag
 hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, int waves, const void *blob,
-                         ProbState *host_st, hipStream_t s) {
+                         ProbState *host_st, hipStream_t s, const T1Team *tm) {
   T1Args a;
   for (int l = 0; l < 16; ++l) a.lc[l] = cams[l < e.nlev ? l : 0];
+  const bool p8 = e.P == 8 && !e.robust;  // the lean 8x8 form; behaviour-changing options run in the any-size form
+  const int team = (tm && p8 && tm->team > 1) ? tm->team : 1;
+  a.team = team;
+  a.team_q = team > 1 ? tm->q : 0x7fffffff;
+  a.team_tag0 = team > 1 ? tm->tag0 : 0;
+  a.team_limit = team > 1 ? tm->limit : 0;
+  a.team_mail = team > 1 ? tm->mail : nullptr;
+  a.team_err = team > 1 ? tm->err : nullptr;
+  if (team > 1) {
+    if (team > kTeamMax || !tm->mail || !tm->err || (long long)tm->q * team < maxpts) return hipErrorInvalidValue;
+    maxpts = std::min(maxpts, tm->q);  // LDS records and patches: this workgroup's share only
+  }
   a.npts_cap = (std::max(maxpts, 1) + 3) & ~3;  // keeps the LDS template arrays 16-byte aligned
   a.dbg = 0;
   a.cap_w = 0;
@@ -892,7 +1055,6 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
 #ifdef ICTR_T1_PROF
   if (const char *d = getenv("ICTR_T1_DBG")) a.dbg = atoi(d);
 #endif
-  const bool p8 = e.P == 8 && !e.robust;  // the lean 8x8 form; behaviour-changing options run in the any-size form
   int tl = 0;
   waves = std::min(std::max(waves, 1), p8 ? kT8MaxWaves : kT1MaxWaves);
   const size_t lds = track1_plan(a.npts_cap, e.n, p8 ? 1 : 0, waves, &tl);
@@ -911,19 +1073,28 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
       }();
       cus = n_cu;
     }
-    const bool lean = e.B > cus && lds <= 60 * 1024;
+    const bool lean = (long long)e.B * team > cus && lds <= 60 * 1024;
+    if (team > 1) {  // several workgroups per problem ("Teams"); the templates of a share always fit the LDS
+      if (!tl) return hipErrorInvalidValue;
+      static size_t gt[4] = {0, 0, 0, 0};
+      if (lean)
+        return e.dopatchnorm ? launch_t1(&k_track1_p8<true, true, true, true>, &gt[0], e, a, waves, lds, s, team)
+                             : launch_t1(&k_track1_p8<true, false, true, true>, &gt[1], e, a, waves, lds, s, team);
+      return e.dopatchnorm ? launch_t1(&k_track1_p8<true, true, false, true>, &gt[2], e, a, waves, lds, s, team)
+                           : launch_t1(&k_track1_p8<true, false, false, true>, &gt[3], e, a, waves, lds, s, team);
+    }
     if (lean) {
       if (e.dopatchnorm)
-        return tl ? launch_t1(&k_track1_p8<true, true, true>, &g[6], e, a, waves, lds, s)
-                  : launch_t1(&k_track1_p8<false, true, true>, &g[7], e, a, waves, lds, s);
-      return tl ? launch_t1(&k_track1_p8<true, false, true>, &g[8], e, a, waves, lds, s)
-                : launch_t1(&k_track1_p8<false, false, true>, &g[9], e, a, waves, lds, s);
+        return tl ? launch_t1(&k_track1_p8<true, true, true, false>, &g[6], e, a, waves, lds, s)
+                  : launch_t1(&k_track1_p8<false, true, true, false>, &g[7], e, a, waves, lds, s);
+      return tl ? launch_t1(&k_track1_p8<true, false, true, false>, &g[8], e, a, waves, lds, s)
+                : launch_t1(&k_track1_p8<false, false, true, false>, &g[9], e, a, waves, lds, s);
     }
     if (e.dopatchnorm)
-      return tl ? launch_t1(&k_track1_p8<true, true, false>, &g[0], e, a, waves, lds, s)
-                : launch_t1(&k_track1_p8<false, true, false>, &g[1], e, a, waves, lds, s);
-    return tl ? launch_t1(&k_track1_p8<true, false, false>, &g[2], e, a, waves, lds, s)
-              : launch_t1(&k_track1_p8<false, false, false>, &g[3], e, a, waves, lds, s);
+      return tl ? launch_t1(&k_track1_p8<true, true, false, false>, &g[0], e, a, waves, lds, s)
+                : launch_t1(&k_track1_p8<false, true, false, false>, &g[1], e, a, waves, lds, s);
+    return tl ? launch_t1(&k_track1_p8<true, false, false, false>, &g[2], e, a, waves, lds, s)
+              : launch_t1(&k_track1_p8<false, false, false, false>, &g[3], e, a, waves, lds, s);
   }
   return tl ? launch_t1(&k_track1<true>, &g[4], e, a, waves, lds, s)
             : launch_t1(&k_track1<false>, &g[5], e, a, waves, lds, s);

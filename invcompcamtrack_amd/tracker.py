@@ -276,6 +276,10 @@ class OdometerClass:
     def set_variant(self, variant):
         check(_lib.load().ictr_odometer_set_variant(self._h, int(variant)))
 
+    def set_team(self, target_points, min_points=0, max_points=1 << 30):
+        """One-launch tracker, team form (ictr_batch_set_team): workgroups per problem = ceil(n / target_points)."""
+        check(_lib.load().ictr_odometer_set_team(self._h, int(target_points), int(min_points), int(max_points)))
+
     def set_robust(self, clean_invisible=False, compositional=False, huber_k=0.0):
         """Behaviour-changing options, off by default (see ictr_batch_set_robust)."""
         flags = (1 if clean_invisible else 0) | (2 if compositional else 0) | (4 if huber_k > 0 else 0)
@@ -364,6 +368,10 @@ class TrackBatch:
 
     def set_variant(self, variant):
         check(_lib.load().ictr_batch_set_variant(self._h, int(variant)))
+
+    def set_team(self, target_points, min_points=0, max_points=1 << 30):
+        """One-launch tracker, team form (ictr_batch_set_team): workgroups per problem = ceil(n / target_points)."""
+        check(_lib.load().ictr_batch_set_team(self._h, int(target_points), int(min_points), int(max_points)))
 
     def set_robust(self, clean_invisible=False, compositional=False, huber_k=0.0):
         """Behaviour-changing options, off by default (see ictr_batch_set_robust)."""
@@ -468,10 +476,16 @@ class TrackBatch:
     def path_name(self):
         """Launch form of the last tracking: per-iteration launches (plain, or replayed as one hipGraph) or the
         one-launch small-problem tracker."""
-        return {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)",
+        name = {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)",
                 2: "k_iter* (per-iteration launches replayed as one hipGraph)",
                 3: "k_track1 (one launch per tracking, begin phase and read-back included)"}.get(
             _lib.load().ictr_batch_last_path(self._h), "?")
+        team = _lib.load().ictr_batch_last_team(self._h)
+        return name + (f" x {team} workgroups per problem" if team > 1 else "")
+
+    def last_team(self):
+        """Workgroups per problem of the last tracking when it ran as one launch (1 otherwise)."""
+        return int(_lib.load().ictr_batch_last_team(self._h))
 
     def set_reduction_buffer(self, dev_ptr):
         check(_lib.load().ictr_batch_set_reduction_buffer(self._h, C.c_void_p(dev_ptr or 0)))

@@ -9,6 +9,8 @@ from invcompcamtrack_amd import synth
 # OR-ed into every Pair's kernel-selection bits (tests/test_gpu_parity.py runs its cases once with the automatic
 # choice -- small problems take the one-launch tracker k_track1 -- and once with bit 13 = per-iteration launches)
 FORCE_VARIANT = 0
+# (target, min, max) points for the one-launch tracker's team form (ictr_batch_set_team), or None = library defaults
+FORCE_TEAM = None
 
 
 class Pair:
@@ -26,6 +28,8 @@ class Pair:
         self.pose = ic.PoseClass(self.cam, self.op)
         self.odo = ic.OdometerClass(self.pose, self.op)
         self.odo.set_variant(variant | FORCE_VARIANT)
+        if FORCE_TEAM is not None:
+            self.odo.set_team(*FORCE_TEAM)
         self.odo.enable_trace()
         self.gpa, self.gpb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
         self.M = self.op.maxpttrack

@@ -1,6 +1,7 @@
 """Latency at the reference's own problem sizes (run_odometer_test.m: a few hundred points, 8x8 or 4x4 patches,
-5 levels): SetPose + TrackPose + poses on the host, GPU (the default selection, the one-launch tracker, the
-per-iteration launches replayed as a hipGraph, the plain per-iteration launches) vs the CPU oracle on the same inputs. VERDICT r01 item 3 bars: 100-point pair <= 0.15 ms, 64 x 300-point batch <= 0.3 ms."""
+5 levels): SetPose + TrackPose + poses on the host, GPU (the default selection -- one launch per tracking, one workgroup
+per problem up to 192 points and a team of workgroups above --, the one-launch tracker forced to ONE workgroup per
+problem, the per-iteration launches replayed as a hipGraph, the plain per-iteration launches) vs the CPU oracle on the same inputs. VERDICT r01 item 3 bars: 100-point pair <= 0.15 ms, 64 x 300-point batch <= 0.3 ms."""
 import json
 import sys
 import time
@@ -20,9 +21,10 @@ def one(w, h, n, psz, lv_f, maxiter, B=1, reps=40, cpu=True):
     pa, pb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
     out = dict(frame=f"{w}x{h}", points=n, problems=B, psz=psz, levels=lv_f + 1, maxiter=maxiter)
     poses = {}
-    forms = (("default", 0), ("one_launch", 16384), ("graph", 8192), ("per_iteration_launches", 8192 | 32768))
+    forms = (("default", 0), ("one_workgroup", 16384 | (1 << 19)), ("graph", 8192),
+             ("per_iteration_launches", 8192 | 32768))
     for name, variant in forms:
-        if name == "one_launch" and n * psz * psz > 2048 * 64:
+        if name == "one_workgroup" and n * psz * psz > 2048 * 64:
             continue
         eng = ic.TrackBatch(cam, op, B)
         eng.set_variant(variant)
@@ -59,7 +61,7 @@ def one(w, h, n, psz, lv_f, maxiter, B=1, reps=40, cpu=True):
 
 
 if __name__ == "__main__":
-    for n in (60, 100, 300, 1000):
+    for n in (60, 100, 300, 1000, 3000):
         one(640, 480, n, 8, 4, 10)
     one(640, 480, 300, 4, 4, 5)
     one(640, 480, 300, 8, 4, 10, B=64, reps=20)
