@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1262,6 +1264,63 @@ static int track1_waves(const ictr_batch *b) {
   return forced > 0 ? forced : 8;
 }
 
+// Admission of team launches. A team's workgroups wait for each other inside the kernel, so they must all become
+// resident. One launch alone is safe whatever its size (in-order dispatch: the lowest unfinished team always gets its
+// CUs). Several team launches on different streams are dispatched interleaved, each with at most ONE partly resident
+// team at its dispatch front; if those fronts could fill every CU, nobody would ever be complete. So the launches in
+// flight (process-wide, any batch, any stream) are kept to sum(team - 1) < CUs: a launch that would exceed it first
+// makes its stream wait (hipStreamWaitEvent, the host does not block) for the oldest team launches still in flight.
+// With teams of at most 64 workgroups and 256 CUs that is four concurrent launches of the largest team, more of smaller.
+struct TeamFlight {
+  hipEvent_t ev;
+  int weight;  // team - 1
+};
+static std::mutex g_team_mu;
+static std::deque<TeamFlight> g_team_flights;   // oldest first
+static std::vector<hipEvent_t> g_team_events;   // recycled events
+static int team_cu_count() {
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+      v = 256;
+    return v;
+  }();
+  return n_cu;
+}
+// before the launch: make `s` wait until this launch fits; returns the event to record behind it (team_admit_done)
+static int team_admit(int team, hipStream_t s, hipEvent_t *ev_out) {
+  std::lock_guard<std::mutex> lk(g_team_mu);
+  while (!g_team_flights.empty() && hipEventQuery(g_team_flights.front().ev) == hipSuccess) {  // retire finished ones
+    g_team_events.push_back(g_team_flights.front().ev);
+    g_team_flights.pop_front();
+  }
+  (void)hipGetLastError();  // hipEventQuery's "not ready" is not an error
+  int load = 0;
+  for (const TeamFlight &f : g_team_flights) load += f.weight;
+  static const int off = env_int("ICTR_TEAM_NO_ADMISSION", 0);  // A/B only: shows what the admission is for
+  const int budget = off ? (1 << 30) : team_cu_count() - 1;
+  for (size_t i = 0; i < g_team_flights.size() && load + (team - 1) > budget; ++i) {
+    HIPCHK(hipStreamWaitEvent(s, g_team_flights[i].ev, 0));  // this launch starts behind flight i
+    load -= g_team_flights[i].weight;
+  }
+  hipEvent_t ev = nullptr;
+  if (!g_team_events.empty()) {
+    ev = g_team_events.back();
+    g_team_events.pop_back();
+  } else {
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  *ev_out = ev;
+  return ICTR_OK;
+}
+static int team_admit_done(int team, hipStream_t s, hipEvent_t ev) {
+  std::lock_guard<std::mutex> lk(g_team_mu);
+  HIPCHK(hipEventRecord(ev, s));
+  g_team_flights.push_back(TeamFlight{ev, team - 1});
+  return ICTR_OK;
+}
+
 // mailbox, tag epoch and error flag of the next team launch (tm->team == 1: not a team launch, nothing allocated)
 static int team_prepare(ictr_batch *b, T1Team *tm) {
   memset(tm, 0, sizeof(*tm));
@@ -1403,7 +1462,12 @@ static int enqueue_levels(ictr_batch *b) {
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
     T1Team tm;
     if (int rc = team_prepare(b, &tm)) return rc;
+    hipEvent_t tev = nullptr;
+    if (tm.team > 1)
+      if (int rc = team_admit(tm.team, b->stream, &tev)) return rc;
     HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream, tm.team > 1 ? &tm : nullptr));
+    if (tm.team > 1)
+      if (int rc = team_admit_done(tm.team, b->stream, tev)) return rc;
     b->last_team = tm.team;
     b->last_path = 1;
     return ICTR_OK;
@@ -1449,8 +1513,13 @@ static int track_enqueue(ictr_batch *b) {
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
     T1Team tm;
     if (int rc = team_prepare(b, &tm)) return rc;
+    hipEvent_t tev = nullptr;
+    if (tm.team > 1)
+      if (int rc = team_admit(tm.team, b->stream, &tev)) return rc;
     HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream,
                          tm.team > 1 ? &tm : nullptr));
+    if (tm.team > 1)
+      if (int rc = team_admit_done(tm.team, b->stream, tev)) return rc;
     b->last_team = tm.team;
     b->last_path = 3;
     mirrored = true;

@@ -325,6 +325,44 @@ def test_team_form_batches_ragged_shares_and_repeated_launches(oracle):
     assert nteam == 22 and close(gots[0][0], refs[0][0])
 
 
+def test_team_launches_on_many_streams_are_admitted_without_starving_each_other(oracle):
+    """A team's workgroups wait for each other inside the kernel, so all of them must become resident. Six engines on
+    six streams, each a lone 2500-point problem shared by 63 workgroups, launched back to back without waiting: their
+    dispatch fronts together (6 x 62) could occupy every CU with partly resident teams. The library admits team launches
+    so that sum(team - 1) stays below the CU count (later launches start behind the oldest ones in flight): every
+    tracking must complete -- no exchange time-out -- with the poses of the same problems run one after the other."""
+    torch = pytest.importorskip("torch")
+    sc = scene(640, 480, 2500, seed=71)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    op = ic.optparam(2, 0, 8, 6, 0.0, 0, 0, 2500)
+    rng = np.random.default_rng(12)
+    poses0 = sc["p_a"][None, :] + rng.normal(0, 1e-3, (6, 6))
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    engines = []
+    for k in range(6):
+        e = ic.TrackBatch(cam, op, 1)
+        e.set_team(40, 0, 1 << 30)
+        e.Set3Dpoints(0, sc["pts3d"].copy())
+        engines.append(e)
+    alone = []
+    for k, e in enumerate(engines):  # one after the other, default stream
+        e.SetPose(0, poses0[k], pa, pb)
+        e.track_async()
+        alone.append(e.poses().copy())
+        assert e.last_team() == 63
+    for k, e in enumerate(engines):
+        e.set_stream(streams[k].cuda_stream)
+    for rep in range(5):
+        for k, e in enumerate(engines):
+            e.SetPose(0, poses0[k], pa, pb)
+        for e in engines:
+            e.track_async()
+        for k, e in enumerate(engines):
+            assert np.array_equal(e.poses(), alone[k]), (rep, k)
+    torch.cuda.synchronize()
+
+
 def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
     """Launch-bound sizes replay the per-iteration launch sequence as one instantiated hipGraph (enqueue_levels): the
     SAME kernels with the SAME arguments, so every bit must agree with the plain launches -- also on the second
