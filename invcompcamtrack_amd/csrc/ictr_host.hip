@@ -1361,7 +1361,7 @@ static int team_prepare(ictr_batch *b, T1Team *tm) {
   }
   static const double limit_s = [] {
     const char *s = getenv("ICTR_TEAM_TIMEOUT_S");
-    return s ? std::max(0.001, atof(s)) : 2.0;
+    return s ? std::max(0.001, atof(s)) : 5.0;
   }();
   tm->tag0 = b->team_epoch << 12;
   tm->limit = (unsigned long long)(limit_s * 1e8);

@@ -446,6 +446,7 @@ __global__ __launch_bounds__(64) void k_iter_finish(EngineDev e, int level, int 
 __device__ __forceinline__ int xcd_band_block(int bx, int gx) { return (gx & 7) ? bx : (bx & 7) * (gx >> 3) + (bx >> 3); }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef const f32x4_t __attribute__((address_space(1))) *gconst_f32x4;
 
 // Packed taps: the setup kernel gathers the SAME 9x9 window from three planes. With the planes interleaved as one
@@ -490,12 +491,17 @@ struct PatchLoads {  // raw load results of one stage-2 step of kU patches (cons
 //   1  the same loads as buffer loads: plane / patch-buffer descriptor in SGPRs, wave-uniform offset in an SGPR,
 //      per-lane constant byte offset in a VGPR -> no vector address arithmetic per load;
 //   2  buffer loads, and every lane loads its own two row pairs (x-1,x at y and y-1): no cross-lane traffic, no
-//      selects; neighbouring lanes' requests hit the same cache lines.
+//      selects; neighbouring lanes' requests hit the same cache lines;
+//   3  as 2 with the per-patch bookkeeping cut down (the form k_track1_p8's patch loop took, ictr_track1.hip): the
+//      LDS record is [w1 w0 w3 w2][cx2..5][cy2..5][cx0 cy1 vis -] -- four ds_read_b128 at one address, operands already
+//      paired for the packed multiply-adds, no re-pairing moves; the window's byte offset is computed per POINT in
+//      stage 1 (one v_readlane per patch, no scalar arithmetic behind it); the padding of a partial pipeline step
+//      points at a zero record (an exact zero contribution to b and to H) instead of being branched around.
 // A wave issues at most one instruction of any kind per ~4 cycles, so at the coarse levels (frames cached) the
 // kernel's pace is its instruction count per patch, not bytes (profiles/r02_notes.md).
 template <bool PN, int kU, bool NT = true, bool WH = false, int LD = 0>  // WH: also accumulate the 21 H sums
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
-  __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
+  __shared__ __attribute__((aligned(16))) float sRec[kWaves][65 * kRec];  // record 64: zeros (LD == 3)
   __shared__ float sW[kWaves][kPartBStride];
   __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
   const int b = blockIdx.y;
@@ -526,10 +532,14 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   const int loff = (lane >> 3) * sw + (lane & 7);
   float *rec = sRec[wave];
   const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
+  if constexpr (LD == 3) {
+    if (lane < kRec) rec[64 * kRec + lane] = 0.0f;  // (first read behind stage 1's wave barrier)
+  }
 
   float acc[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
+  f32x2_t acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}, acc45 = {0.0f, 0.0f};  // LD == 3: the same six sums as pairs
   float accH[WH ? kHUnique : 1];
 #pragma unroll
   for (int j = 0; j < (WH ? kHUnique : 1); ++j) accH[j] = 0.0f;
@@ -552,7 +562,14 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
     const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
     const int base_v = tp.row0 * sw + tp.col0;
-    {
+    const int so_v = (base_v - sw - 1) * 4;  // LD == 3: bytes to the window's top-left texel (tap d of pixel 0)
+    if constexpr (LD == 3) {
+      float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
+      r4[0] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
+      r4[1] = make_float4(q0.z, q0.w, q1.x, q1.y);  // cx2 cx3 cx4 cx5
+      r4[2] = make_float4(q2.x, q2.y, q2.z, q2.w);  // cy2 cy3 cy4 cy5
+      r4[3] = make_float4(q0.x, q1.w, vis ? 1.0f : 0.0f, 0.0f);  // cx0 cy1 vis -
+    } else {
       float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
       r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
       // [cx0 cy1 | cx2 cx3][cy2 cy3 | cx4 cx5][cy4 cy5 | vis -]: operand pairs of the packed multiply-adds below
@@ -571,6 +588,19 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
       for (int u = 0; u < kU; ++u) {
         const int jraw = sidx + u * nsteps;
         const int jj = min(jraw, cnt - 1);
+        if constexpr (LD == 3) {
+          constexpr int aux = NT ? 2 : 0;
+          L.rec[u] = (jraw < cnt) ? jj : 64;  // padding: the zero record; its loads repeat the chunk's last patch
+          const int so = rlane(so_v, jj);
+          const int po4 = (i0 + jj) * 256;
+          const int off_cd = ((lane >> 3) * sw + (lane & 7)) * 4, off_ab = off_cd + sw * 4;
+          L.t[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, lane * 4, po4, aux));
+          L.gx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, lane * 4, po4, aux));
+          L.gy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, lane * 4, po4, aux));
+          L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_ab, so, 0));
+          L.cur[u].top = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_cd, so, 0));
+          continue;
+        }
         L.rec[u] = (jraw < cnt) ? jj : -1;
         const int base = rlane(base_v, jj);
         if constexpr (LD == 0) {
@@ -603,6 +633,41 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     auto reduce = [&](const PatchLoads<kU> &L) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
+        if constexpr (LD == 3) {
+          // (compiler barrier tied to the accumulators: keeps the four record reads of patch u behind the sums of patch
+          // u - 1 -- hoisted together they cost 64 registers and two waves of occupancy)
+          asm volatile("" : "+v"(acc01), "+v"(acc23), "+v"(acc45) : : "memory");
+          const float4 *r4 = rec4 + L.rec[u] * 4;
+          const float4 wv = r4[0], qx = r4[1], qy = r4[2], qz = r4[3];
+          // utilities.cpp:107 in the reference's operand order, never contracted: ((w0 a + w1 b) + w2 c) + w3 d
+          float inew = wv.y * L.cur[u].ab.y + wv.x * L.cur[u].ab.x + wv.w * L.cur[u].top.y + wv.z * L.cur[u].top.x;
+          if constexpr (PN) inew -= wave_sum(inew) / 64.0f;  // utilities.cpp:111-112
+          const float gx = L.gx[u], gy = L.gy[u];
+          const float r = (L.t[u] - inew) * qz.z;  // pdiff (odometer.cpp:381); 0 out of view and for padding
+          // the J^T r (and H) sums are compared to tolerance only: explicit multiply-adds
+          // (as register PAIRS: v_pk_fma_f32 does two of the six sums per instruction)
+          const f32x2_t g2 = {gx * r, gy * r}, gr2 = {g2.x, g2.x}, hr2 = {g2.y, g2.y};
+          acc01 = __builtin_elementwise_fma(g2, (f32x2_t){qz.x, qz.y}, acc01);  // sd1 = Gx cx0, sd2 = Gy cy1
+          acc23 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.x, qx.y},         // sd3..sd6 = Gx cxk + Gy cyk
+                                            __builtin_elementwise_fma(hr2, (f32x2_t){qy.x, qy.y}, acc23));
+          acc45 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.z, qx.w},         // (odometer.cpp:319-326)
+                                            __builtin_elementwise_fma(hr2, (f32x2_t){qy.z, qy.w}, acc45));
+          if constexpr (WH) {  // H = sum sd_j sd_k over every stored patch, visible or stale (odometer.cpp:428-455);
+            float sd[6];       // the padding record's coefficients are zero: an exact zero contribution
+            sd[0] = gx * qz.x;
+            sd[1] = gy * qz.y;
+            sd[2] = __builtin_fmaf(gx, qx.x, gy * qy.x);
+            sd[3] = __builtin_fmaf(gx, qx.y, gy * qy.y);
+            sd[4] = __builtin_fmaf(gx, qx.z, gy * qy.z);
+            sd[5] = __builtin_fmaf(gx, qx.w, gy * qy.w);
+            int jk = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c = a; c < 6; ++c, ++jk) accH[jk] = __builtin_fmaf(sd[a], sd[c], accH[jk]);
+          }
+          continue;
+        }
         if (L.rec[u] < 0) continue;  // wave-uniform
         const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
                      k2 = rec4[L.rec[u] * 4 + 3];
@@ -652,6 +717,9 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     __builtin_amdgcn_wave_barrier();  // the records are rewritten by the next chunk
   }
 
+  if constexpr (LD == 3) {
+    acc[0] = acc01.x, acc[1] = acc01.y, acc[2] = acc23.x, acc[3] = acc23.y, acc[4] = acc45.x, acc[5] = acc45.y;
+  }
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const float v = wave_sum(acc[k]);
@@ -1616,20 +1684,27 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
     // patches per pipeline step: 4 measured best (profiles/r01_notes.md); variant bits 4-5 select others for A/B
     const int ku = (variant >> 4) & 3;
     // stage-2 addressing (see k_iter8): buffer loads + per-lane taps (LD = 2) measured best (r02: levels 1 / 2 195 ->
-    // 183 / 182 -> 165 us per launch); variant bits 16-17 = 1 / 2 select LD = 0 / 1 for A/B
+    // 183 / 182 -> 165 us per launch), LD = 3 trims its per-patch bookkeeping; variant bits 16-17 = 1 / 2 / 3 select
+    // LD = 0 / 1 / 2 for A/B
     const int ldsel = (variant >> 16) & 3;
     if (first && defer_h(e, variant)) {
-      if (e.dopatchnorm)
+      if (e.dopatchnorm && ldsel == 3)
         hipLaunchKernelGGL((k_iter8<true, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      else if (e.dopatchnorm)
+        hipLaunchKernelGGL((k_iter8<true, 2, true, true, 3>), g8, blk, 0, s, e, lc, level, cpw);
       else if (ldsel == 1)
         hipLaunchKernelGGL((k_iter8<false, 4, true, true, 0>), g8, blk, 0, s, e, lc, level, cpw);
       else if (variant & (1 << 20))  // A/B: four patches per step like the regular launches (116 VGPRs, occupancy 4)
         hipLaunchKernelGGL((k_iter8<false, 4, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
-      else  // the H-accumulating launch carries 21 more accumulators: two patches per step keep it at 81 VGPRs /
-            // occupancy 5 (r02: 258 -> 195 us wall per 16-pair launch beside the other engine, step 6.34 -> 6.30 ms)
+      else if (ldsel == 3)
         hipLaunchKernelGGL((k_iter8<false, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
-    } else if (e.dopatchnorm)
+      else  // the H-accumulating launch carries 21 more accumulators: two patches per step keep it at ~81 VGPRs /
+            // occupancy 5 (r02: 258 -> 195 us wall per 16-pair launch beside the other engine, step 6.34 -> 6.30 ms)
+        hipLaunchKernelGGL((k_iter8<false, 2, true, true, 3>), g8, blk, 0, s, e, lc, level, cpw);
+    } else if (e.dopatchnorm && ldsel == 3)
       hipLaunchKernelGGL((k_iter8<true, 2, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_iter8<true, 2, true, false, 3>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 1)
       hipLaunchKernelGGL((k_iter8<false, 1, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 2)
@@ -1640,8 +1715,10 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
       hipLaunchKernelGGL((k_iter8<false, 4, true, false, 0>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ldsel == 2)
       hipLaunchKernelGGL((k_iter8<false, 4, true, false, 1>), g8, blk, 0, s, e, lc, level, cpw);
-    else
+    else if (ldsel == 3)
       hipLaunchKernelGGL((k_iter8<false, 4, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+    else
+      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 3>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (fast4(e, variant)) {
     const dim3 g8(gridx8, e.B);
     if (first) {
