@@ -442,11 +442,13 @@ def test_updates_match_the_summation_order_free_cpu_path(oracle, w, h, npts, psz
     assert np.abs(po - pg).max() <= POSE_TOL
 
 
-@pytest.mark.parametrize("B,psz", [(1, 8), (3, 8), (2, 4), (1, 5)])
-def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz):
+@pytest.mark.parametrize("B,psz,team", [(1, 8, 0), (3, 8, 0), (2, 4, 0), (1, 5, 0), (1, 8, 16), (3, 8, 24)])
+def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz, team):
     """Small batches go out as ONE launch that carries ictr_batch_begin's device part in its arguments and writes the
     final states into the pinned host mirror (track_enqueue): every bit -- poses, iteration counts, the projections
-    Get2DPoints returns, the stored state -- must equal the form with separate uploads / projection launch / copy."""
+    Get2DPoints returns, the stored state -- must equal the form with separate uploads / projection launch / copy.
+    team > 0: the same with every problem shared by workgroups of `team` points each (every workgroup projects its own
+    points in the prologue, the first one stores the tables and the final state)."""
     sc = scene(256, 224, 90, seed=40 + psz, margin=float(max(12, psz + 9)))
     op = ic.optparam(3, 0, psz, 6, 0.0, 0, 0, 90)
     cam = ic.CamClass(4, sc["fc"], sc["cc"], sc["wh"], psz)
@@ -455,6 +457,8 @@ def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz):
     for variant in (0, SEPARATE_BEGIN):
         e = ic.TrackBatch(cam, op, B)
         e.set_variant(variant)
+        if team:
+            e.set_team(team, 0, 1 << 30)
         for k in range(B):
             e.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :90 - 7 * k].copy()))
         res = []
@@ -465,6 +469,7 @@ def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz):
             res.append((e.poses().copy(), e.iterations().copy(), [e.Get2DPoints(k).copy() for k in range(B)],
                         [e.read_buffer(k, 8, 40) for k in range(B)]))
         out.append((res, e.path_name()))
+        assert ("workgroups per problem" in e.path_name()) == bool(team), e.path_name()
     assert "begin phase" in out[0][1] and "begin phase" not in out[1][1], (out[0][1], out[1][1])
     for ra, rb in zip(out[0][0], out[1][0]):
         assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
@@ -478,6 +483,8 @@ def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz):
             pose = ic.PoseClass(cam1, op)
             odo = ic.OdometerClass(pose, op)
             odo.set_variant(variant)
+            if team:
+                odo.set_team(team, 0, 1 << 30)
             odo.Set3Dpoints(sc["pts3d"].copy())
             odo.SetPose(sc["p_a"], pa, pb)
             p2 = odo.Get2DPoints().copy()
