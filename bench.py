@@ -680,6 +680,35 @@ def main():
                                    [float(x) / nl * 1e3 for x in ev_iters] if not sharded else None,
                                "per_level_setup_us":
                                    [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_setup] if not sharded else None}
+            if overlapping and not sharded and streams[0] is not None:
+                # Cross-check without any overlap: the SAME engines and launches (same kernels, same grids: what
+                # rocprofv3 --stats lists under the same names) on ONE stream, so every launch runs alone and its plain
+                # HIP-event duration is the machine time its bytes needed. Not part of the timed region.
+                h0 = holders[0]
+                for e_ in h0.engs:
+                    e_.set_stream(streams[0].cuda_stream)
+                solo_sum, solo_first, solo_steps = 0.0, 0.0, 3
+                for _ in range(solo_steps + 1):
+                    h0.setpose_all()
+                    h0.track()
+                    h0.poses()
+                    if _ == 0:
+                        continue  # warm-up of the single-stream order
+                    for e_ in h0.engs:
+                        solo_sum += float(e_.kernel_times().sum())
+                        solo_first += float(e_.first_iter_times().sum())
+                n_solo = solo_steps * n_eng_step * args.maxiter * args.levels
+                t_solo = solo_sum / max(n_solo, 1) * 1e-3
+                out["roofline"]["solo_check"] = {
+                    "us_per_launch": t_solo * 1e6, "achieved": alg / t_solo / 1e9, "frac": alg / t_solo / 1e9 / 8000.0,
+                    "launches_timed": n_solo,
+                    "regular_launch_us": (solo_sum - solo_first) / max(solo_steps * n_eng_step * (args.maxiter - 1) * args.levels, 1) * 1e3,
+                    "first_iteration_launch_us": solo_first / max(solo_steps * n_eng_step * args.levels, 1) * 1e3,
+                    "basis": "the same engines and launches on ONE stream after the timed region (nothing overlaps): "
+                             "mean HIP-event duration of every k_iter8 launch; comparable to rocprofv3 --stats of "
+                             "`bench.py --streams 1` at half the bytes per launch (profiles/r02_streams1_*)"}
+                for e_, st in zip(h0.engs, streams):
+                    e_.set_stream(st.cuda_stream)
         pose_fail = False
         if args.cpu_seconds > 0 and world == 1 and not sharded:
             # the same tracking on the CPU path (the oracle: checker and baseline, never the product): problem 0 is
