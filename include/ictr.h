@@ -195,7 +195,10 @@ int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double 
  *   bit 12 (4096)  three separate reference planes instead of the packed {img,dx,dy,0} texels
  *   bit 13 (8192)  per-iteration launches whatever the problem size; bit 14 (16384) the one-launch tracker;
  *   bit 15 (32768) plain launches instead of the hipGraph replay; bit 18 (262144) begin phase as separate operations;
- *   bit 19 (524288) one workgroup per problem in the one-launch tracker (no teams, see ictr_batch_set_team) */
+ *   bit 19 (524288) one workgroup per problem in the one-launch tracker (no teams, see ictr_batch_set_team)
+ *   bit 21 (2097152) never the resident-iteration form (all iterations of a level in one launch, templates in
+ *                  registers: the default for up to 8 dense frame pairs of >= 8193 8x8 patches); bit 23 (8388608) that
+ *                  form whatever the batch size */
 int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
 /* one-launch tracker, team form (see ictr_batch_set_team) */
 int ictr_odometer_set_team(ictr_odometer *odo, int target_points, int min_points, int max_points);

@@ -42,6 +42,11 @@ void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
 hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t,
                          const T1Team *);
+hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, unsigned, unsigned long long,
+                                 unsigned long long *, int *, hipStream_t);
+size_t resident_mail_bytes(int, int);
+int resident_points_per_workgroup(void);
+int resident_blocks_per_cu(void);
 int track1_team_q(int, int);
 int track1_team_size(int, int);
 size_t track1_team_mail_bytes(int, int);
@@ -764,6 +769,10 @@ struct ictr_batch {
   unsigned long long *d_team_mail = nullptr;  // granule mailboxes [B][2][team][32]; allocated on first use
   size_t team_mail_bytes = 0;
   unsigned team_epoch = 0;    // tags of a launch: epoch << 12 | exchange number
+  // resident-iteration form (ictr_resident.hip): all iterations of a level in one launch, templates in registers
+  unsigned long long *d_res_mail = nullptr;  // per slot: gather box + broadcast box
+  size_t res_mail_bytes = 0;
+  unsigned res_epoch = 0;
   int last_team = 1;          // workgroups per problem of the last one-launch tracking
   int team_target = 0;        // points per workgroup aimed at (0: automatic, < 0: no teams); ictr_batch_set_team
   int team_lo = 128, team_hi = 8192;  // problem sizes (points) served by teams: lo < maxpts <= hi
@@ -790,6 +799,7 @@ static void batch_free(ictr_batch *b) {
   if (b->h_up_pin) (void)hipHostFree(b->h_up_pin);
   if (b->h_team_err) (void)hipHostFree(b->h_team_err);
   if (b->d_team_mail) (void)hipFree(b->d_team_mail);
+  if (b->d_res_mail) (void)hipFree(b->d_res_mail);
   b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
@@ -1376,8 +1386,13 @@ static int team_prepare(ictr_batch *b, T1Team *tm) {
 // kernel launches and the GPU finds the next packet already queued. The graph is captured once per batch and reused for
 // as long as nothing the launches depend on changes (kernel arguments are passed by value: pointers, sizes, options,
 // camera, grid shapes -- all of it goes into the key). Variant bit 15 (32768) keeps the plain launches (A/B).
+struct ResPlan {  // resident-iteration form (below): worker workgroups per frame pair, pairs in flight; 0 = not this form
+  int parts = 0, slots = 0;
+};
+static ResPlan resident_plan(const ictr_batch *b);
 static bool use_graph(const ictr_batch *b) {
   if (b->sharded || b->timing || b->graph_broken || (engine_variant(b) & 32768)) return false;
+  if (resident_plan(b).parts > 0) return false;  // three launches per level, admission events: nothing to replay
   static const int64_t limit = [] {
     const char *s = getenv("ICTR_GRAPH_MAXPTS");  // total points of a batch up to which the graph is used; 0 = never
     return s ? (int64_t)atoll(s) : (int64_t)65536;
@@ -1406,10 +1421,101 @@ static std::string graph_key(const ictr_batch *b, const EngineDev &e) {
   return k;
 }
 
+// Resident-iteration form (ictr_resident.hip): problems of thousands of 8x8 patches run all iterations of a level in
+// ONE launch with their templates resident in registers -- `parts` worker workgroups of 128 points + one solver
+// workgroup per frame pair, `slots` pairs in flight (two workgroups per CU) -- instead of streaming T/Gx/Gy from HBM in
+// every iteration. Needs every workgroup of the launch resident at once: slots * (parts + 1) <= CUs * occupancy.
+// An iteration is then a latency chain of ~10 us per pair with two pairs in flight: the form of choice for ONE or a few
+// dense frame pairs (one 1080p pair: 0.62 against 1.21 ms; 8 pairs 1.7 against 2.2), while a large batch on two
+// streams is served as well by the streaming kernels at the HBM roofline (32 pairs: 6.5 against 6.2 ms), so the
+// default is this form up to ICTR_RESIDENT_MAXB = 8 pairs per engine. Variant bit 21 (2097152) or ICTR_RESIDENT=0:
+// never; variant bit 23 (8388608): whatever the batch size (A/B).
+static ResPlan resident_plan(const ictr_batch *b) {
+  ResPlan p;
+  static const int on = env_int("ICTR_RESIDENT", 1);
+  static const int min_pts = env_int("ICTR_RESIDENT_MINPTS", 8193);  // below: the one-launch tracker's team form
+  const int v = engine_variant(b);
+  if (!on || (v & ((1 << 21) | 8192)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !b->packed)
+    return p;
+  if (b->maxpts < min_pts || b->op->maxiter < 1) return p;
+  static const int max_b = env_int("ICTR_RESIDENT_MAXB", 8);
+  if (b->B > max_b && !(v & (1 << 23))) return p;
+  const int bpc = resident_blocks_per_cu();
+  if (bpc < 1) return p;
+  const int q = resident_points_per_workgroup();
+  const int parts = (b->maxpts + q - 1) / q;
+  const int64_t capacity = (int64_t)bpc * team_cu_count();
+  static const int max_slots = env_int("ICTR_RESIDENT_SLOTS", 1 << 20);  // experiments: pairs in flight per launch
+  const int slots = (int)std::min<int64_t>(std::min<int64_t>(b->B, max_slots), capacity / (parts + 1));
+  if (slots < 1) return p;
+  if ((int64_t)((b->B + slots - 1) / slots) * b->op->maxiter >= 4000) return p;  // exchange number: 12 bits of the tag
+  p.parts = parts;
+  p.slots = slots;
+  return p;
+}
+// one level's iterations as ONE resident launch (behind the level's setup launches on the same stream)
+static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc, int level, const ResPlan &p,
+                           hipStream_t s) {
+  const size_t need = resident_mail_bytes(p.parts, p.slots);
+  if (need > b->res_mail_bytes) {
+    if (b->d_res_mail) {
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(hipFree(b->d_res_mail));
+      b->d_res_mail = nullptr;
+      b->res_mail_bytes = 0;
+    }
+    hipError_t er = hipExtMallocWithFlags((void **)&b->d_res_mail, need, hipDeviceMallocUncached);
+    if (er != hipSuccess) {
+      (void)hipGetLastError();
+      er = hipMalloc((void **)&b->d_res_mail, need);
+    }
+    if (er == hipSuccess) er = hipMemsetAsync(b->d_res_mail, 0, need, s);  // tag 0: "nothing yet"
+    if (er != hipSuccess) return fail(ICTR_ERR_HIP, "resident mailbox allocation failed: %s", hipGetErrorString(er));
+    b->res_mail_bytes = need;
+    b->res_epoch = 0;
+  }
+  if (!b->h_team_err) {
+    HIPCHK(hipHostMalloc((void **)&b->h_team_err, sizeof(int), hipHostMallocDefault));
+    *b->h_team_err = 0;
+    HIPCHK(hipHostGetDevicePointer((void **)&b->d_team_err, b->h_team_err, 0));
+  }
+  b->res_epoch += 1;
+  if (b->res_epoch >= (1u << 20)) {
+    HIPCHK(hipMemsetAsync(b->d_res_mail, 0, b->res_mail_bytes, s));
+    b->res_epoch = 1;
+  }
+  static const double limit_s = [] {
+    const char *t = getenv("ICTR_TEAM_TIMEOUT_S");
+    return t ? std::max(0.001, atof(t)) : 5.0;
+  }();
+  // the launch wants every CU slot: it starts behind every team / resident launch in flight and the next ones behind it
+  hipEvent_t tev = nullptr;
+  if (int rc = team_admit(team_cu_count(), s, &tev)) return rc;
+  HIPCHK(launch_level_resident(e, lc, level, p.parts, p.slots, b->res_epoch << 12, (unsigned long long)(limit_s * 1e8),
+                               b->d_res_mail, b->d_team_err, s));
+  return team_admit_done(team_cu_count(), s, tev);
+}
+
 // split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket
 // the accumulate kernel alone
 static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t s, bool events) {
   const int mi = b->op->maxiter;
+  const ResPlan rp = resident_plan(b);
+  if (rp.parts > 0) {  // the setup launches (H included), then ONE launch for all iterations of the level
+    for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
+      const LevelCam lc = level_cam(b->cam, sl);
+      if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
+      launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 22), b->cpw, b->gridx8, s);
+      if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
+      if (int rc = launch_resident(b, e, lc, sl, rp, s)) return rc;
+      if (events) {
+        HIPCHK(hipEventRecord(b->ev[3 * sl + 2], s));
+        b->ev_used[sl] = 1;
+      }
+    }
+    b->last_path = 4;
+    return ICTR_OK;
+  }
   const bool tk = events && (int)b->evk.size() >= 2 * b->nlev * mi && mi <= b->evk_iters;
   for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
     const LevelCam lc = level_cam(b->cam, sl);

@@ -1651,6 +1651,13 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
         hipLaunchKernelGGL((k_ref8<false, 4, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
       else
         hipLaunchKernelGGL((k_ref8<false, 1, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+    } else if (pk && !e.dopatchnorm && (variant & (1 << 22))) {
+      // H summed by the setup kernel itself, from the packed planes (the resident-iteration form, ictr_resident.hip,
+      // has no H-accumulating first iteration launch); variant bits 6-7 = 2: one patch per pipeline step
+      if (ku == 2)
+        hipLaunchKernelGGL((k_ref8<false, 1, true, true, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
+      else
+        hipLaunchKernelGGL((k_ref8<false, 2, true, true, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
     } else if (e.dopatchnorm)
       hipLaunchKernelGGL((k_ref8<true, 1>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
     else if (ku == 1)

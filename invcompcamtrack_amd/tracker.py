@@ -478,7 +478,8 @@ class TrackBatch:
         one-launch small-problem tracker."""
         name = {0: "k_iter* (per-iteration launches)", 1: "k_track1 (one launch per tracking)",
                 2: "k_iter* (per-iteration launches replayed as one hipGraph)",
-                3: "k_track1 (one launch per tracking, begin phase and read-back included)"}.get(
+                3: "k_track1 (one launch per tracking, begin phase and read-back included)",
+                4: "k_level_resident (one launch per level: all iterations, templates resident in registers)"}.get(
             _lib.load().ictr_batch_last_path(self._h), "?")
         team = _lib.load().ictr_batch_last_team(self._h)
         return name + (f" x {team} workgroups per problem" if team > 1 else "")

@@ -46,6 +46,8 @@ ONE_LAUNCH = 16384  # variant bit 14: the one-launch tracker k_track1 (default c
 SEPARATE_BEGIN = 1 << 18  # variant bit 18: uploads, projection launch and read-back copy as separate operations
 NO_GRAPH = 32768  # variant bit 15: the per-iteration launches as plain launches (default below 65 536 points: one hipGraph)
 NO_TEAMS = 1 << 19  # variant bit 19: the one-launch tracker with ONE workgroup per problem whatever its size
+NO_RESIDENT = 1 << 21  # variant bit 21: never the resident-iteration form (k_level_resident)
+RESIDENT = 1 << 23  # variant bit 23: the resident-iteration form whatever the batch size (default: up to 8 pairs)
 
 
 @pytest.fixture(params=["one_launch", "teams", "launches"])
@@ -363,6 +365,47 @@ def test_team_launches_on_many_streams_are_admitted_without_starving_each_other(
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B,ratio,maxiter", [(1, 0.0, 6), (3, 0.0, 6), (5, 0.01, 10), (2, 0.0, 1)])
+def test_resident_iterations_equal_per_iteration_launches(oracle, B, ratio, maxiter):
+    """k_level_resident (all iterations of a level in ONE launch: templates resident in registers / LDS, a mailbox
+    gather + broadcast per iteration, one solver workgroup per frame pair) against the per-iteration launches: problems
+    of 8300-9000 points with different counts (the last worker workgroups of a pair partly or wholly without points),
+    more pairs than pairs in flight (a slot walks through several pairs), repeated launches (tag epochs), early exit
+    (normdp_ratio 0.01: the loop flag travels with the pose) and a single iteration. Same setup kernels => patches and
+    coefficients bit-identical; H and b by another summation order => poses to float noise, iteration counts equal."""
+    sc = scene(640, 480, 9000, seed=83)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    op = ic.optparam(2, 0, 8, maxiter, ratio, 0, 0, 9000)
+    counts = [9000 - 173 * k for k in range(B)]
+    poses0 = sc["p_a"][None, :] + np.random.default_rng(9).normal(0, 1e-3, (B, 6))
+    out = {}
+    for name, variant in (("resident", RESIDENT), ("launches", NO_RESIDENT)):
+        e = ic.TrackBatch(cam, op, B)
+        e.set_variant(variant)
+        for k in range(B):
+            e.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :counts[k]].copy()))
+        runs = []
+        for rep_, (ra, rb) in enumerate(((pa, pb), (pa, pb), (pb, pa))):
+            e.SetPoseAll(poses0, ra, rb)
+            e.track_async()
+            runs.append((e.poses().copy(), e.iterations().copy(),
+                         [e.read_buffer(k, w, 64 * counts[k]) for k in range(B) for w in (0, 1, 2)],
+                         [e.read_buffer(k, 7, 16 * counts[k]) for k in range(B)]))
+        out[name] = (runs, e.path_name())
+    assert "k_level_resident" in out["resident"][1] and "k_iter" in out["launches"][1], (out["resident"][1], out["launches"][1])
+    for r, l in zip(out["resident"][0], out["launches"][0]):
+        # 640 px frames: the tap-selection quirk of the module docstring; with an exit threshold a level may also end one
+        # iteration earlier in one form (the last steps are ~1e-4)
+        assert np.abs(r[0] - l[0]).max() <= (2e-5 if ratio == 0.0 else 2e-4)
+        if ratio == 0.0:
+            assert np.array_equal(r[1], l[1])
+        assert all(np.array_equal(x, y) for x, y in zip(r[2], l[2])), "patch buffers differ between the launch forms"
+        assert all(np.array_equal(x, y) for x, y in zip(r[3], l[3])), "sd coefficients differ between the launch forms"
+    a, b_ = out["resident"][0][0], out["resident"][0][1]
+    assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]), "the same launch twice must give the same bits"
+
+
 def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
     """Launch-bound sizes replay the per-iteration launch sequence as one instantiated hipGraph (enqueue_levels): the
     SAME kernels with the SAME arguments, so every bit must agree with the plain launches -- also on the second
@@ -406,14 +449,16 @@ def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
 
 
 @pytest.mark.parametrize("w,h,npts,psz,dp_tol", [(640, 480, 4000, 8, 1e-5), (256, 224, 150, 8, 1e-4),
-                                                  (640, 480, 6000, 4, 1e-5)])
+                                                  (640, 480, 6000, 4, 1e-5), (256, 224, 9000, 8, 1e-5)])
 def test_updates_match_the_summation_order_free_cpu_path(oracle, w, h, npts, psz, dp_tol, launch_form):
     """per-iteration delta_p relative error <= 1e-5. Two float32 paths that add ~10^5-10^6 products in
     different orders cannot agree to that (the solve amplifies the sums' 1e-6..1e-5 by cond(H) ~ 1e4), so the yardstick
     is the CPU path with its whole-buffer sums accumulated in float64 (orc_set_sum_mode: same float32 products, same
     solver, same pose update -- only the summation order no longer matters). Against it the HIP path's first update
     (bit-identical inputs) is held to 1e-5 relative (1e-4 for the 150-point case: the float32 LU of a system with
-    cond(H) ~ 1e5 carries that much on its own), H and b to 1e-6; the pose trajectory to 2e-5 absolute."""
+    cond(H) ~ 1e5 carries that much on its own), H and b to 1e-6; the pose trajectory to 2e-5 absolute. The 9000-point
+    case is a single dense problem: by default (everything but the "launches" form) it runs as k_level_resident -- all
+    iterations of a level in one launch, H summed by the setup kernel."""
     if launch_form != "launches" and psz != 8 and npts * psz * psz > 512 * 64:
         pytest.skip("the one-launch tracker takes large problems as teams of 8x8-patch workgroups only")
     sc = scene(w, h, npts, seed=90 + psz, margin=float(max(12, psz + 9)))
@@ -570,7 +615,8 @@ def test_one_launch_tracker_is_the_default_for_small_batches(oracle):
     big = scene(640, 368, 9000, seed=22)
     pba, pbb = ic.Pyramid(big["img_a"], 1, 8), ic.Pyramid(big["img_b"], 1, 8)
     camb = ic.CamClass(2, big["fc"], big["cc"], big["wh"], 8)
-    for npts, want, team in ((9000, "k_iter", 1), (3000, "k_track1", 63), (300, "k_track1", 8), (128, "k_track1", 1)):
+    for npts, want, team in ((9000, "k_level_resident", 1), (3000, "k_track1", 63), (300, "k_track1", 8),
+                             (128, "k_track1", 1)):
         opb = ic.optparam(1, 0, 8, 2, 0.0, 0, 0, npts)
         bb = ic.TrackBatch(camb, opb, 1)
         bb.Set3Dpoints(0, np.ascontiguousarray(big["pts3d"][:, :npts].copy()))
