@@ -1283,7 +1283,7 @@ static int track1_waves(const ictr_batch *b) {
 // With teams of at most 64 workgroups and 256 CUs that is four concurrent launches of the largest team, more of smaller.
 struct TeamFlight {
   hipEvent_t ev;
-  int weight;  // team - 1
+  int weight;  // half-CU slots, see team_admit
 };
 static std::mutex g_team_mu;
 static std::deque<TeamFlight> g_team_flights;   // oldest first
@@ -1299,7 +1299,10 @@ static int team_cu_count() {
   return n_cu;
 }
 // before the launch: make `s` wait until this launch fits; returns the event to record behind it (team_admit_done)
-static int team_admit(int team, hipStream_t s, hipEvent_t *ev_out) {
+// weight, in half-CU slots (two workgroups of the 128-register builds share a CU): a team launch 2 (team - 1) -- its
+// partly resident dispatch front, a whole CU per workgroup --, a resident-iteration launch one per workgroup (ALL of
+// them must be resident). Budget 2 CUs - 2: sum(team - 1) < CUs as before; two resident launches of CUs - 1 workgroups fit.
+static int team_admit(int weight, hipStream_t s, hipEvent_t *ev_out) {
   std::lock_guard<std::mutex> lk(g_team_mu);
   while (!g_team_flights.empty() && hipEventQuery(g_team_flights.front().ev) == hipSuccess) {  // retire finished ones
     g_team_events.push_back(g_team_flights.front().ev);
@@ -1309,8 +1312,8 @@ static int team_admit(int team, hipStream_t s, hipEvent_t *ev_out) {
   int load = 0;
   for (const TeamFlight &f : g_team_flights) load += f.weight;
   static const int off = env_int("ICTR_TEAM_NO_ADMISSION", 0);  // A/B only: shows what the admission is for
-  const int budget = off ? (1 << 30) : team_cu_count() - 1;
-  for (size_t i = 0; i < g_team_flights.size() && load + (team - 1) > budget; ++i) {
+  const int budget = off ? (1 << 30) : 2 * team_cu_count() - 2;
+  for (size_t i = 0; i < g_team_flights.size() && load + weight > budget; ++i) {
     HIPCHK(hipStreamWaitEvent(s, g_team_flights[i].ev, 0));  // this launch starts behind flight i
     load -= g_team_flights[i].weight;
   }
@@ -1324,10 +1327,10 @@ static int team_admit(int team, hipStream_t s, hipEvent_t *ev_out) {
   *ev_out = ev;
   return ICTR_OK;
 }
-static int team_admit_done(int team, hipStream_t s, hipEvent_t ev) {
+static int team_admit_done(int weight, hipStream_t s, hipEvent_t ev) {
   std::lock_guard<std::mutex> lk(g_team_mu);
   HIPCHK(hipEventRecord(ev, s));
-  g_team_flights.push_back(TeamFlight{ev, team - 1});
+  g_team_flights.push_back(TeamFlight{ev, weight});
   return ICTR_OK;
 }
 
@@ -1488,12 +1491,13 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
     const char *t = getenv("ICTR_TEAM_TIMEOUT_S");
     return t ? std::max(0.001, atof(t)) : 5.0;
   }();
-  // the launch wants every CU slot: it starts behind every team / resident launch in flight and the next ones behind it
+  // every workgroup of the launch must be resident: it starts when its slots are free of team / resident launches
+  const int weight = p.slots * (p.parts + 1) * (resident_blocks_per_cu() >= 2 ? 1 : 2);
   hipEvent_t tev = nullptr;
-  if (int rc = team_admit(team_cu_count(), s, &tev)) return rc;
+  if (int rc = team_admit(weight, s, &tev)) return rc;
   HIPCHK(launch_level_resident(e, lc, level, p.parts, p.slots, b->res_epoch << 12, (unsigned long long)(limit_s * 1e8),
                                b->d_res_mail, b->d_team_err, s));
-  return team_admit_done(team_cu_count(), s, tev);
+  return team_admit_done(weight, s, tev);
 }
 
 // split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket
@@ -1570,10 +1574,10 @@ static int enqueue_levels(ictr_batch *b) {
     if (int rc = team_prepare(b, &tm)) return rc;
     hipEvent_t tev = nullptr;
     if (tm.team > 1)
-      if (int rc = team_admit(tm.team, b->stream, &tev)) return rc;
+      if (int rc = team_admit(2 * (tm.team - 1), b->stream, &tev)) return rc;
     HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream, tm.team > 1 ? &tm : nullptr));
     if (tm.team > 1)
-      if (int rc = team_admit_done(tm.team, b->stream, tev)) return rc;
+      if (int rc = team_admit_done(2 * (tm.team - 1), b->stream, tev)) return rc;
     b->last_team = tm.team;
     b->last_path = 1;
     return ICTR_OK;
@@ -1621,11 +1625,11 @@ static int track_enqueue(ictr_batch *b) {
     if (int rc = team_prepare(b, &tm)) return rc;
     hipEvent_t tev = nullptr;
     if (tm.team > 1)
-      if (int rc = team_admit(tm.team, b->stream, &tev)) return rc;
+      if (int rc = team_admit(2 * (tm.team - 1), b->stream, &tev)) return rc;
     HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream,
                          tm.team > 1 ? &tm : nullptr));
     if (tm.team > 1)
-      if (int rc = team_admit_done(tm.team, b->stream, tev)) return rc;
+      if (int rc = team_admit_done(2 * (tm.team - 1), b->stream, tev)) return rc;
     b->last_team = tm.team;
     b->last_path = 3;
     mirrored = true;

@@ -6,6 +6,7 @@
   C4          BASELINE config 4: 4096 independent 31x31 patches on a 1080p pair, 3 levels (flow producer)
   nposes      run_track_nposes' shape (run_ransac_test.m:67,88): 500 pose samples x 60 points, 10 frame pairs
   small       one 100-point frame pair at the reference's own size (run_odometer_test.m), latency
+  dense       ONE dense 1080p frame pair per tracking (the headline's pair, unbatched): resident-iteration form
   pyramid     util_constructpyramide (utilities.cpp:14-52) of a 1080p frame, 3 levels, refilled in place per frame
 
 Every record carries its own algorithmic bytes, the measured kernel time (HIP events on the launching stream) and
@@ -194,6 +195,53 @@ def rec_nposes(seconds):
             "pose_err_vs_ground_truth_median": float(np.median(np.abs(p - sc["p_a"][None, :]).max(1)))}
 
 
+def rec_dense(seconds):
+    """The headline's frame pair as the reference would run it: ONE dense 1080p pair (and a batch of 4) per tracking,
+    SetPose + TrackPose + poses on the host. Default = k_level_resident (all iterations of a level in one launch,
+    templates resident on the chip); the streaming per-iteration kernels beside it (variant bit 21)."""
+    import invcompcamtrack_amd as ic
+    from invcompcamtrack_amd import synth
+    w, h, lv_f, P = 1920, 1080, 2, 8
+    sc = synth.make_scene(w, h, grid_step=P, margin=P / 2.0, jitter=0.35, seed=100)  # the headline's scene 0
+    n = sc["pts3d"].shape[1]
+    op = ic.optparam(lv_f, 0, P, 10, 0.0, 0, 0, n)
+    cam = ic.CamClass(lv_f + 1, sc["fc"], sc["cc"], sc["wh"], P)
+    pa, pb = ic.Pyramid(sc["img_a"], lv_f, P), ic.Pyramid(sc["img_b"], lv_f, P)
+    cases = []
+    for B in (1, 4):
+        row = {"pairs": B, "points_per_pair": n}
+        for name, variant in (("default", 0), ("streaming", 1 << 21)):
+            eng = ic.TrackBatch(cam, op, B)
+            eng.set_variant(variant)
+            for k in range(B):
+                eng.Set3Dpoints(k, sc["pts3d"].copy())
+            p_all = np.tile(sc["p_a"], (B, 1))
+
+            def step():
+                eng.SetPoseAll(p_all, pa, pb)
+                eng.track_async()
+                return eng.poses()
+
+            step()
+            ts = []
+            t_end = time.perf_counter() + seconds / 4
+            while len(ts) < 5 or (time.perf_counter() < t_end and len(ts) < 100):
+                t0 = time.perf_counter()
+                p = step()
+                ts.append(time.perf_counter() - t0)
+            row[name + "_ms"] = float(np.median(ts)) * 1e3
+            row[name + "_kernel"] = eng.path_name()
+            row[name + "_pose_err_vs_ground_truth"] = float(np.abs(p - sc["p_b"][None, :]).max())
+        cases.append(row)
+    pix = 30.0 * n * P * P
+    return {"name": "dense", "workload": f"ONE dense {w}x{h} frame pair per tracking ({n} 8x8 patches, 3 levels x 10 "
+            "iterations), host calls included; and a batch of 4", "value": cases[0]["default_ms"], "unit": "ms per tracking "
+            "(1 pair)", "aligned_Mpix_per_s": pix / (cases[0]["default_ms"] * 1e-3) / 1e6, "cases": cases,
+            "kernel": cases[0]["default_kernel"], "algorithmic_bytes_per_launch": None, "frac": None,
+            "note": "latency regime: an iteration is a ~10 us chain (patches from registers, mailbox gather, solve, "
+                    "broadcast), not a stream of T/Gx/Gy from HBM"}
+
+
 def rec_small(seconds):
     import invcompcamtrack_amd as ic
     out = []
@@ -270,7 +318,7 @@ def rec_pyramid(seconds):
 
 def run_all(seconds=1.0):
     recs = []
-    for fn in (rec_psz4, rec_c3, rec_c5, rec_c4, rec_nposes, rec_small, rec_pyramid):
+    for fn in (rec_psz4, rec_c3, rec_c5, rec_c4, rec_nposes, rec_small, rec_dense, rec_pyramid):
         t0 = time.perf_counter()
         try:
             r = fn(seconds)
