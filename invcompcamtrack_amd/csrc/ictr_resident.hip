@@ -3,24 +3,28 @@
 //
 // The per-iteration kernel k_iter8 streams T, Gx, Gy of every patch from HBM in every iteration: 12 of its 16 bytes
 // per pixel, ten times per level, and it runs at the HBM roofline doing so (profiles/r02_notes.md). But a frame pair's
-// templates are only 25 MB per level -- the chip has 128 MB of vector registers. Here a frame pair is shared by
-// `parts` workgroups (128 points each: sixteen patches per wave, T/Gx/Gy of a patch = three registers of its wave,
-// lane = pixel), which load their templates ONCE per level and keep them for all iterations of odometer.cpp:344-418;
-// an iteration then reads only the current frame's windows (cache-resident) and exchanges 12 numbers per workgroup:
+// templates are only 25 MB per level -- the chip has 128 MB of vector registers and 40 MB of LDS. Here a frame pair is
+// shared by `parts` worker workgroups (128 points each: sixteen patches per wave; Gx and Gy of a patch = two registers
+// of its wave, lane = pixel; T in LDS), which load their templates ONCE per level and keep them for all iterations of
+// odometer.cpp:344-418; an iteration then reads only the current frame's windows (cache-resident) and exchanges 12
+// numbers per workgroup:
 //
 //   every workgroup   stage 1  one point per lane (lanes 0-15 of a wave): projection at the current pose
 //                              (pose.cpp:384-391), ind_new (odometer.cpp:369-377), bilinear weights + window offset
 //                     stage 2  sixteen patches per wave from registers: current-frame window (utilities.cpp:55-113),
 //                              residual, J^T r (odometer.cpp:381-404) in six per-lane accumulators
 //                     gather   the workgroup's six sums (as hi/lo float pairs) -> the pair's mailbox
-//   workgroup 0       all eight waves poll the mailbox (32 workgroups each, one round trip), fixed-order f64 sum, then
+//   the pair's solver workgroup (no templates: its registers never compete with the resident ones)
+//                     all eight waves poll the mailbox (32 workers each, one round trip), fixed-order f64 sum, then
 //                     ONE wave: substitution with the level's LU factors, pose update, exp map, loop condition
 //                     (odometer.cpp:407-418, 509-515; WaveSolver, ictr_devfn.h) -> broadcast of cpos_G + loop flag
-//   every workgroup   polls the broadcast, next iteration
+//   every worker      polls the broadcast, next iteration
 //
 // Two hops per iteration instead of two kernel boundaries and 33 MB of HBM traffic per pair. An iteration is a serial
-// chain of ~7 us for ONE pair, so `slots` pairs are in flight at once (two workgroups per CU, 128 registers each) and
-// the chains of different pairs overlap on the same SIMDs; every slot walks through its share of the batch's pairs.
+// chain of ~9.4 us for ONE pair (tools/resprof.py), so `slots` pairs are in flight at once (two workgroups per CU, 128
+// registers each) and the chains of different pairs overlap on the same SIMDs (two in flight: +10 % per chain); every
+// slot walks through its share of the batch's pairs. Measured: one 1080p pair 0.62 ms against 1.21 with the streaming
+// kernels; the default for up to 8 pairs per engine (ictr_host.hip, resident_plan).
 // The mailbox protocol is the one of the team form (ictr_track1.hip "Teams"): 8-byte granules {float bits, tag},
 // tags = launch epoch << 12 | exchange number, double-buffered by parity, bounded polling with a sticky error flag.
 // H is accumulated and factored by the level's setup launches (k_ref8<.., WH = true> + k_level_tail), the templates
