@@ -203,8 +203,12 @@ __device__ __forceinline__ void reduce_partH(const EngineDev &e, int b, int nblk
     const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
     double s = 0.0;
     const float *ph = e.partH + (size_t)b * nblk * kPartHStride + j;
-    if (j < kHUnique)
+    // (unrolled: eight loads in flight, the additions stay in the same order -- with thousands of partials, e.g. one
+    // dense 1080p pair in 4-point chunks, the serial load latency of this loop was 60 us per level)
+    if (j < kHUnique) {
+#pragma unroll 8
       for (int k = sl; k < nblk; k += kBlock / 32) s += (double)ph[(size_t)k * kPartHStride];
+    }
     sRed[sl][j] = s;
   }
   __syncthreads();
@@ -375,8 +379,10 @@ __global__ __launch_bounds__(kBlock) void k_iter_tail(EngineDev e, int level, in
     const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
     double s = 0.0;
     const float *pb = e.partb + (size_t)b * nblk * kPartBStride + j;
-    if (j < 6)
+    if (j < 6) {
+#pragma unroll 8
       for (int k = sl; k < nblk; k += kBlock / 8) s += (double)pb[(size_t)k * kPartBStride];
+    }
     sRed[sl][j] = s;
   }
   __syncthreads();
