@@ -462,8 +462,10 @@ __global__ __launch_bounds__(kBlock) void k_icgn_hess_tail(IcDev e, int nblk, in
   if (!finish_only) {
     const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
     double s = 0.0;
-    if (j < NH)
+    if (j < NH) {  // (eight loads in flight, additions in the same order: the loop is pure load latency otherwise)
+#pragma unroll 8
       for (int k = sl; k < nblk; k += kBlock / 64) s += (double)e.partH[((size_t)b * nblk + k) * kIcPartH + j];
+    }
     sRed[sl][j] = s;
     __syncthreads();
     if (threadIdx.x < NH) {
@@ -516,8 +518,10 @@ __global__ __launch_bounds__(kBlock) void k_icgn_iter_tail(IcDev e, float f_leve
   if (!finish_only) {
     const int j = threadIdx.x & 7, sl = threadIdx.x >> 3;
     double s = 0.0;
-    if (j < N)
+    if (j < N) {
+#pragma unroll 8
       for (int k = sl; k < nblk; k += kBlock / 8) s += (double)e.partb[((size_t)b * nblk + k) * kIcPartB + j];
+    }
     sRed[sl][j] = s;
     __syncthreads();
     if (threadIdx.x < N) {
