@@ -58,6 +58,8 @@ struct IcState {
   float b[8];
   float dp[8];
   int it, active, total_iters, pad_[2];
+  float Hinv[64];  // H^-1 (row-major), computed once per level when H has full rank (hinv_ok); see k_icgn_hess_tail
+  int hinv_ok, pad2_[3];
 };
 
 struct IcLevel {
@@ -503,7 +505,25 @@ __global__ __launch_bounds__(kBlock) void k_icgn_hess_tail(IcDev e, int nblk, in
     for (int k = 0; k < 2 * N; ++k) st.piv[k] = sI[k];
     st.luinfo[0] = sI[16];
     st.luinfo[1] = sI[17];
+    st.hinv_ok = (sI[17] == N) ? 1 : 0;
     ic_level_reset(st, e);
+  }
+  // Full rank (the normal case): the inverse once per level -- thread j solves for the unit vector e_j with the factors
+  // just stored -- so that an iteration's solve is N dot products on N threads instead of one thread's substitution
+  // through LDS arrays (the classic inverse-compositional form keeps H^-1 too). Rank-deficient: the iterations keep
+  // the full-pivot substitution and its particular solution.
+  __syncthreads();
+  __shared__ float sUnit[8][24];  // per solving thread: right-hand side [0..7], solution [8..15], workspace [16..23]
+  if (threadIdx.x < N && sI[17] == N) {
+    float *u = sUnit[threadIdx.x];
+    for (int k = 0; k < N; ++k) u[k] = (k == (int)threadIdx.x) ? 1.0f : 0.0f;
+    switch (N) {
+      case 2: lu_apply_ws<2>(sFull, sI, sI + 16, u, u + 8, u + 16); break;
+      case 3: lu_apply_ws<3>(sFull, sI, sI + 16, u, u + 8, u + 16); break;
+      case 6: lu_apply_ws<6>(sFull, sI, sI + 16, u, u + 8, u + 16); break;
+      default: lu_apply_ws<8>(sFull, sI, sI + 16, u, u + 8, u + 16); break;
+    }
+    for (int r = 0; r < N; ++r) st.Hinv[r * N + threadIdx.x] = u[8 + r];  // column j of the inverse
   }
 }
 
@@ -537,18 +557,30 @@ __global__ __launch_bounds__(kBlock) void k_icgn_iter_tail(IcDev e, float f_leve
     sLU[64 + threadIdx.x] = e.red[(size_t)b * kIcRed + kIcNH + threadIdx.x];
     e.red[(size_t)b * kIcRed + kIcNH + threadIdx.x] = 0.0f;
   }
-  if (threadIdx.x < N * N) sLU[threadIdx.x] = st.LU[threadIdx.x];
+  const int use_inv = st.hinv_ok;  // workgroup-uniform
   __shared__ int sI[20];
-  if (threadIdx.x < 2 * N) sI[threadIdx.x] = st.piv[threadIdx.x];
-  if (threadIdx.x < 2) sI[16 + threadIdx.x] = st.luinfo[threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x != 0) return;
   float *dpf = sLU + 80;  // keep every runtime-indexed array in LDS (no scratch)
-  switch (N) {
-    case 2: lu_apply_ws<2>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
-    case 3: lu_apply_ws<3>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
-    case 6: lu_apply_ws<6>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
-    default: lu_apply_ws<8>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
+  if (use_inv) {
+    __syncthreads();  // b in sLU[64..]
+    if (threadIdx.x < N) {  // dp_j = sum_k Hinv[j][k] b[k], one row per thread
+      float d = 0.0f;
+      for (int k = 0; k < N; ++k) d += st.Hinv[threadIdx.x * N + k] * sLU[64 + k];
+      dpf[threadIdx.x] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+  } else {
+    if (threadIdx.x < N * N) sLU[threadIdx.x] = st.LU[threadIdx.x];
+    if (threadIdx.x < 2 * N) sI[threadIdx.x] = st.piv[threadIdx.x];
+    if (threadIdx.x < 2) sI[16 + threadIdx.x] = st.luinfo[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    switch (N) {
+      case 2: lu_apply_ws<2>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
+      case 3: lu_apply_ws<3>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
+      case 6: lu_apply_ws<6>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
+      default: lu_apply_ws<8>(sLU, sI, sI + 16, sLU + 64, dpf, sLU + 72); break;
+    }
   }
   const double sc = 2.0 / (double)f_level;
   double nrm = 0.0;
