@@ -42,7 +42,7 @@ void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
 hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t,
                          const T1Team *);
-hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, unsigned, unsigned long long,
+hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, int, unsigned, unsigned long long,
                                  unsigned long long *, int *, hipStream_t);
 size_t resident_mail_bytes(int, int);
 int resident_points_per_workgroup(void);
@@ -1438,7 +1438,7 @@ static ResPlan resident_plan(const ictr_batch *b) {
   static const int on = env_int("ICTR_RESIDENT", 1);
   static const int min_pts = env_int("ICTR_RESIDENT_MINPTS", 8193);  // below: the one-launch tracker's team form
   const int v = engine_variant(b);
-  if (!on || (v & ((1 << 21) | 8192)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !b->packed)
+  if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !b->packed)
     return p;
   if (b->maxpts < min_pts || b->op->maxiter < 1) return p;
   static const int max_b = env_int("ICTR_RESIDENT_MAXB", 8);
@@ -1495,8 +1495,8 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
   const int weight = p.slots * (p.parts + 1) * (resident_blocks_per_cu() >= 2 ? 1 : 2);
   hipEvent_t tev = nullptr;
   if (int rc = team_admit(weight, s, &tev)) return rc;
-  HIPCHK(launch_level_resident(e, lc, level, p.parts, p.slots, b->res_epoch << 12, (unsigned long long)(limit_s * 1e8),
-                               b->d_res_mail, b->d_team_err, s));
+  HIPCHK(launch_level_resident(e, lc, level, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
+                               (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, s));
   return team_admit_done(weight, s, tev);
 }
 

@@ -46,6 +46,7 @@ struct ResArgs {
   LevelCam lc;
   int level;
   int parts, slots;          // worker workgroups per frame pair; pairs in flight (grid = slots * (parts + 1))
+  int nblk;                  // workgroups per problem of the level's setup launch (their H partials: e.partH)
   unsigned tag0;             // launch epoch << 12
   unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
   unsigned long long *mail;  // per slot: gather box [2][parts][kResSlot], then broadcast box [2][16]
@@ -149,16 +150,55 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
     // ================================================================ the pair's solver workgroup
     SolveOpts sopt = solve_opts(e);
     sopt.robust = 0;
+    __shared__ double sRedH[64 * kResWaves / 32][32];
+    __shared__ float sH[32];
     for (int b = slot; b < e.B; b += a.slots) {
       const ProbState &gst = e.st[b];
-      int active = gst.active;  // loop condition of odometer.cpp:344-346, reset by the level's tail launch (uniform)
-      if (!active) continue;
+      // loop condition of odometer.cpp:341-346 at the start of a level: normdp / normdp_init = 1 (every workgroup of the
+      // pair evaluates it for itself; maxiter >= 1 is the host's condition for this form)
+      int active = ((0 < e.maxiter) & (1.0f > e.ratio)) ? 1 : 0;
       {
         const unsigned *src = reinterpret_cast<const unsigned *>(&gst);
         unsigned *dst = reinterpret_cast<unsigned *>(&sSt);
         for (int i = tid; i < (int)(sizeof(ProbState) / 4); i += blockDim.x) dst[i] = src[i];
       }
+      // ---- what k_level_tail does in the other launch forms: fixed-order f64 sum of the setup launch's H partials
+      // (16 slices x 32 components, then the slices in order), full-pivot LU once per level, loop state reset --
+      // while the pair's workers load their templates
+      {
+        const int j = tid & 31, sl = tid >> 5;
+        double sacc = 0.0;
+        const float *ph = e.partH + (size_t)b * a.nblk * kPartHStride + j;
+        if (j < kHUnique) {
+#pragma unroll 8
+          for (int k = sl; k < a.nblk; k += 64 * kResWaves / 32) sacc += (double)ph[(size_t)k * kPartHStride];
+        }
+        sRedH[sl][j] = sacc;
+      }
       __syncthreads();
+      if (tid < kHUnique) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 64 * kResWaves / 32; ++sl) sacc += sRedH[sl][tid];
+        sH[tid] = (float)sacc;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        WaveSolver S;
+        ws_factor(S, sH[h_unique_index(lane)], lane);
+        ws_store_factor(S, sSt, lane);
+        if (lane == 0) level_reset(sSt, e);
+      }
+      __syncthreads();
+      if (!active) {  // nothing to iterate: the state (H, factors, reset loop state) still goes back
+        if (wave == 0) {
+          const unsigned *src = reinterpret_cast<const unsigned *>(&sSt);
+          unsigned *dst = reinterpret_cast<unsigned *>(e.st + b);
+          for (int i = lane; i < (int)(sizeof(ProbState) / 4); i += 64) dst[i] = src[i];
+        }
+        __syncthreads();
+        continue;
+      }
       while (active) {
         seq += 1;
         const unsigned tag = a.tag0 + seq;
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
   for (int b = slot; b < e.B; b += a.slots) {
     const ProbState &gst = e.st[b];
     const int npts = gst.npts;
-    int active = gst.active;
+    int active = ((0 < e.maxiter) & (1.0f > e.ratio)) ? 1 : 0;  // as the solver workgroup evaluates it (odometer.cpp:341-346)
     if (!active) continue;
     const int i0 = part * kResQ + wave * kResPPW;
     const int cnt = min(kResPPW, max(0, npts - i0));  // this wave's points (wave-uniform)
@@ -414,10 +454,11 @@ int resident_blocks_per_cu(void) {
   }();
   return n;
 }
-hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int parts, int slots,
+hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int parts, int slots, int nblk,
                                  unsigned tag0, unsigned long long limit, unsigned long long *mail, int *err,
                                  hipStream_t s) {
   ResArgs a;
+  a.nblk = nblk;
   a.lc = lc;
   a.level = level;
   a.parts = parts;
