@@ -1429,7 +1429,7 @@ static std::string graph_key(const ictr_batch *b, const EngineDev &e) {
 // workgroup per frame pair, `slots` pairs in flight (two workgroups per CU) -- instead of streaming T/Gx/Gy from HBM in
 // every iteration. Needs every workgroup of the launch resident at once: slots * (parts + 1) <= CUs * occupancy.
 // An iteration is then a latency chain of ~10 us per pair with two pairs in flight: the form of choice for ONE or a few
-// dense frame pairs (one 1080p pair: 0.49 against 0.74 ms; 8 pairs 1.66 against 1.82), while a large batch on two
+// dense frame pairs (one 1080p pair: 0.42 against 0.72 ms; 8 pairs 1.66 against 1.82), while a large batch on two
 // streams is served as well by the streaming kernels at the HBM roofline (32 pairs: 6.5 against 6.2-6.4 ms), so the
 // default is this form up to ICTR_RESIDENT_MAXB = 8 pairs per engine. Variant bit 21 (2097152) or ICTR_RESIDENT=0:
 // never; variant bit 23 (8388608): whatever the batch size (A/B).

@@ -23,12 +23,13 @@
 // Two hops per iteration instead of two kernel boundaries and 33 MB of HBM traffic per pair. An iteration is a serial
 // chain of ~9.4 us for ONE pair (tools/resprof.py), so `slots` pairs are in flight at once (two workgroups per CU, 128
 // registers each) and the chains of different pairs overlap on the same SIMDs (two in flight: +10 % per chain); every
-// slot walks through its share of the batch's pairs. Measured: one 1080p pair 0.49 ms against 0.74 with the streaming
+// slot walks through its share of the batch's pairs. Measured: one 1080p pair 0.42 ms against 0.72 with the streaming
 // kernels; the default for up to 8 pairs per engine (ictr_host.hip, resident_plan).
 // The mailbox protocol is the one of the team form (ictr_track1.hip "Teams"): 8-byte granules {float bits, tag},
 // tags = launch epoch << 12 | exchange number, double-buffered by parity, bounded polling with a sticky error flag.
-// H is accumulated and factored by the level's setup launches (k_ref8<.., WH = true> + k_level_tail), the templates
-// and the (possibly stale) coefficients come from the buffers those launches wrote: patches, coefficients and
+// H is accumulated by the level's setup launch (k_ref8<.., WH = true, PK = true>: per-workgroup partials) and reduced +
+// factored by the pair's solver workgroup at the start of the pair (what k_level_tail does in the other launch forms),
+// the templates and the (possibly stale) coefficients come from the buffers that launch wrote: patches, coefficients and
 // projections are bit-identical to the other launch forms, b differs by summation order only.
 #include "ictr_dev.h"
 #include "ictr_devfn.h"
