@@ -748,6 +748,7 @@ struct ictr_batch {
   std::vector<char> ev_used;
   std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
   int evk_iters = 0;
+  bool evk_valid = true;  // the per-iteration kernel events of the last tracking were recorded (not in the resident form)
   int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
   int maxpts = 0;    // largest nopoints over the problems of the current tracking (set by ictr_batch_begin)
   int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip), 2: launches replayed as a graph,
@@ -1517,10 +1518,12 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
         b->ev_used[sl] = 1;
       }
     }
+    b->evk_valid = false;  // no per-iteration launches: the kernel-time getters report zeros
     b->last_path = 4;
     return ICTR_OK;
   }
   const bool tk = events && (int)b->evk.size() >= 2 * b->nlev * mi && mi <= b->evk_iters;
+  b->evk_valid = tk;
   for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
     const LevelCam lc = level_cam(b->cam, sl);
     if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
@@ -1693,7 +1696,7 @@ extern "C" int ictr_batch_get_kernel_times(ictr_batch *b, float *ms_kernel) {
   const int mi = std::min(b->op->maxiter, b->evk_iters);
   for (int l = 0; l < b->nlev; ++l) {
     ms_kernel[l] = 0.0f;
-    if (!b->ev_used[l]) continue;
+    if (!b->ev_used[l] || !b->evk_valid) continue;
     for (int it = 0; it < mi; ++it) {
       float ms = 0.0f;
       HIPCHK(hipEventElapsedTime(&ms, b->evk[2 * (l * b->evk_iters + it)], b->evk[2 * (l * b->evk_iters + it) + 1]));
@@ -1710,7 +1713,7 @@ extern "C" int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first) {
   if (int rc = batch_wait(b)) return rc;
   for (int l = 0; l < b->nlev; ++l) {
     ms_first[l] = 0.0f;
-    if (!b->ev_used[l] || b->op->maxiter < 1) continue;
+    if (!b->ev_used[l] || !b->evk_valid || b->op->maxiter < 1) continue;
     HIPCHK(hipEventElapsedTime(&ms_first[l], b->evk[2 * (l * b->evk_iters)], b->evk[2 * (l * b->evk_iters) + 1]));
   }
   return ICTR_OK;
@@ -1736,7 +1739,7 @@ extern "C" int ictr_batch_get_kernel_intervals(ictr_batch *b, float *start_ms, f
     for (int it = 0; it < b->evk_iters; ++it) {
       const int k = l * b->evk_iters + it;
       start_ms[k] = end_ms[k] = 0.0f;
-      if (!b->ev_used[l] || it >= mi) continue;
+      if (!b->ev_used[l] || !b->evk_valid || it >= mi) continue;
       HIPCHK(hipEventElapsedTime(&start_ms[k], g_timebase, b->evk[2 * k]));
       HIPCHK(hipEventElapsedTime(&end_ms[k], g_timebase, b->evk[2 * k + 1]));
     }
