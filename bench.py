@@ -690,7 +690,7 @@ def main():
                                    [float(x) / nl * 1e3 for x in ev_iters] if not sharded else None,
                                "per_level_setup_us":
                                    [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_setup] if not sharded else None}
-            if overlapping and not sharded and streams[0] is not None:
+            if overlapping and not sharded and streams[0] is not None and not resident_form:
                 # Cross-check without any overlap: the SAME engines and launches (same kernels, same grids: what
                 # rocprofv3 --stats lists under the same names) on ONE stream, so every launch runs alone and its plain
                 # HIP-event duration is the machine time its bytes needed. Not part of the timed region.
