@@ -406,6 +406,42 @@ def test_resident_iterations_equal_per_iteration_launches(oracle, B, ratio, maxi
     assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]), "the same launch twice must give the same bits"
 
 
+def test_resident_and_team_launches_share_the_gpu(oracle):
+    """The two in-launch-synchronised forms on different streams at the same time: two engines with one dense
+    9000-point pair each (k_level_resident: every workgroup of a launch must be resident) and two with a 2500-point
+    problem (a team of 63 workgroups), launched back to back without waiting, five times. The admission keeps the
+    launches in flight within the chip's workgroup slots; every tracking must complete (no exchange time-out) with
+    exactly the poses of the same problems run one after the other."""
+    torch = pytest.importorskip("torch")
+    sc = scene(640, 480, 9000, seed=72)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    rng = np.random.default_rng(13)
+    engines, want = [], []
+    for k, npts in enumerate((9000, 2500, 9000, 2500)):
+        op = ic.optparam(2, 0, 8, 6, 0.0, 0, 0, npts)
+        e = ic.TrackBatch(cam, op, 1)
+        e._op_keep = op
+        e.Set3Dpoints(0, np.ascontiguousarray(sc["pts3d"][:, :npts].copy()))
+        p0 = sc["p_a"] + rng.normal(0, 1e-3, 6)
+        e.SetPose(0, p0, pa, pb)
+        e.track_async()
+        want.append((p0, e.poses().copy()))
+        assert ("k_level_resident" if npts == 9000 else "workgroups per problem") in e.path_name(), e.path_name()
+        engines.append(e)
+    streams = [torch.cuda.Stream() for _ in engines]
+    for e, st in zip(engines, streams):
+        e.set_stream(st.cuda_stream)
+    for rep in range(5):
+        for e, (p0, _) in zip(engines, want):
+            e.SetPose(0, p0, pa, pb)
+        for e in engines:
+            e.track_async()
+        for k, (e, (_, p)) in enumerate(zip(engines, want)):
+            assert np.array_equal(e.poses(), p), (rep, k)
+    torch.cuda.synchronize()
+
+
 def test_graph_replay_equals_plain_launches_and_follows_option_changes(oracle):
     """Launch-bound sizes replay the per-iteration launch sequence as one instantiated hipGraph (enqueue_levels): the
     SAME kernels with the SAME arguments, so every bit must agree with the plain launches -- also on the second
