@@ -1510,7 +1510,7 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
       const LevelCam lc = level_cam(b->cam, sl);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
-      launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 22), b->cpw, b->gridx8, s);
+      launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 22) | (1 << 24), b->cpw, b->gridx8, s);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
       if (int rc = launch_resident(b, e, lc, sl, rp, s)) return rc;
       if (events) {

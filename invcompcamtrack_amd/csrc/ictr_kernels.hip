@@ -1684,7 +1684,8 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
     hipLaunchKernelGGL(k_ref_level<0>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
   // (the resident-iteration launch that follows reduces and factors H itself: its solver workgroups are idle while the
   // workers load their templates)
-  if (!(fast8(e, variant) && (variant & (1 << 22)) && !dh && e.packed && !e.dopatchnorm && !(variant & 4096)))
+  if (!(fast8(e, variant) && (variant & (1 << 24)) && (variant & (1 << 22)) && !dh && e.packed && !e.dopatchnorm &&
+        !(variant & 4096)))  // bit 24: set by the host's resident path only
     hipLaunchKernelGGL(k_level_tail, dim3(e.B), blk, 0, s, e, nblk, dh ? 1 : 0);
 }
 void launch_level_finish(const EngineDev &e, int variant, hipStream_t s) {
