@@ -1725,7 +1725,7 @@ void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gri
     else if (ku == 1)
       hipLaunchKernelGGL((k_iter8<false, 1, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 2)
-      hipLaunchKernelGGL((k_iter8<false, 2, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+      hipLaunchKernelGGL((k_iter8<false, 2, true, false, 3>), g8, blk, 0, s, e, lc, level, cpw);
     else if (ku == 3)
       hipLaunchKernelGGL((k_iter8<false, 4, false, false, 2>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal loads
     else if (ldsel == 1)
