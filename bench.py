@@ -18,11 +18,13 @@ iteration kernel -- and two such step holders alternate, so that the host prepar
 
   value        = aligned pixels / s  (pixels entering the residual, all levels, all problems, all ranks) in Mpix/s
   roofline     = the GN-iteration kernel k_iter8: algorithmic bytes (16 B per patch pixel: T, Gx, Gy, one
-                 current-frame texel) per launch / duration of a launch, measured with HIP events on
-                 the kernel's stream around every launch of the timed steps, vs 8 TB/s HBM3E. With concurrent
-                 engines a launch's wall-clock duration includes the time it shared the GPU with the other stream's
-                 launches, so the duration used is the FAIR SHARE (union busy time of all k_iter8 intervals / number
-                 of launches; roofline.duration_basis); the wall duration rocprofv3 --stats shows is reported beside it.
+                 current-frame texel) per launch / duration of a launch running ALONE, measured with
+                 HIP events on the kernel's stream around every launch, vs 8 TB/s HBM3E. With two concurrent engines
+                 the timed launches overlap the other stream's kernels, so the same engines and launches run once more
+                 on ONE stream right after the timed region and roofline.frac is THAT un-overlapped figure
+                 (profiles/recompute_roofline.py derives the same number from the rocprofv3 kernel trace of the same
+                 command); roofline.fair_share keeps the overlapped region's figure, roofline.end_to_end all algorithmic
+                 bytes of a step (iterations 16 B/px + setup 24 B/px) over ms_per_step.
   cpu_baseline = the oracle (C restatement of the reference, one thread, -O3 -msse4 -mavx) timed on the same
                  workload for one frame pair (a bounded sample), on this host's cores.
 
@@ -238,6 +240,27 @@ def cpu_baseline(args, scene, n_pts):
             "sample": f"{runs} full trackings of one {args.width}x{args.height} frame pair ({n_pts} points, "
                       f"{args.levels} levels x {args.maxiter} iterations), {t_used:.1f} s; oracle/libictr_oracle.so "
                       f"(C restatement of the reference, gcc -O3 -msse4 -mavx, 1 thread of {os.cpu_count()})"}
+
+
+def cpu_track(scene, lv_f, psz, maxiter, ratio, n_pts, seconds=0.3, p_start=None, img_pair=None, max_runs=200):
+    """cpu_baseline leg for the secondary records: the oracle (one thread) on ONE tracking of `scene` -> (pose, ms per
+    tracking, runs). Pyramids are built outside the timed part, like the GPU records' device pyramids."""
+    from oracle import oracle as O
+    op = O.make_op(lv_f, 0, psz, maxiter, ratio, 0, 0, n_pts)
+    ia, ib = img_pair if img_pair is not None else (scene["img_a"], scene["img_b"])
+    pa, pb = O.Pyramid(ia, lv_f, psz), O.Pyramid(ib, lv_f, psz)
+    tr = O.Tracker(op, scene["fc"], scene["cc"], scene["wh"])
+    p0 = scene["p_a"] if p_start is None else p_start
+    runs, t_used, p = 0, 0.0, None
+    while runs < 1 or (t_used < seconds and runs < max_runs):
+        pts = scene["pts3d"].copy()
+        t0 = time.perf_counter()
+        tr.set3dpoints(pts)
+        tr.setpose(p0, pa, pb)
+        p = np.array(tr.trackpose(), np.float64)
+        t_used += time.perf_counter() - t0
+        runs += 1
+    return p, t_used / runs * 1e3, runs
 
 
 def dp_vs_cpu(ic, args, scene, n_pts, cpu_trace):
@@ -592,10 +615,8 @@ def main():
             pairs_per_launch = eng_list[0].B           # pairs per engine: B / streams (B / groups in the sharded mode)
             n_eng_step = len(eng_list)
             overlapping = n_eng_step > 1               # launches of different engines share the GPU
-            # The first iteration launch of a level is its own instantiation (k_iter8<..,WH=true>: it also accumulates
-            # the 21 H sums that the setup kernel used to produce) and is reported separately; the roofline is that of
-            # the regular instantiation, launches 2..maxiter of every level (what rocprofv3 --stats lists as
-            # k_iter8<false, 4, true, false>).
+            # (Since r03 a level's first iteration launch is the same instantiation as the others -- H comes from the
+            # setup kernel's three sums per patch -- but it is still reported separately: it starts on cold caches.)
             n_reg = args.steps * n_eng_step * (args.maxiter - 1) * args.levels
             n_first = args.steps * n_eng_step * args.levels
             nl = args.steps * n_eng_step * args.maxiter
@@ -658,67 +679,87 @@ def main():
             n_iv = max(len(intervals), 1)
             t_fair = charged * 1e-3 / n_iv if (overlapping and intervals) else t_all   # s per launch, fair share
             busy = charged
-            out["roofline"] = {"bound": "hbm", "achieved": alg / t_fair / 1e9, "peak": 8000.0, "unit": "GB/s",
-                               "frac": alg / t_fair / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+            # roofline.frac = the UN-OVERLAPPED figure: bytes of a launch / the duration of that launch running alone
+            # (one stream: the timed launches themselves; two streams: the same engines and launches once more on ONE
+            # stream right after the timed region, `solo` below). The fair-share figure of the overlapped timed region
+            # is kept as roofline.fair_share (it charges k_iter8 half of every interval it shares with the other
+            # stream's setup kernel whoever used the HBM, and cannot be recomputed from a --stats summary).
+            solo = None
+            if overlapping and not sharded and streams[0] is not None and not resident_form:
+                h0 = holders[0]
+                for e_ in h0.engs:
+                    e_.set_stream(streams[0].cuda_stream)
+                solo_sum, solo_first, solo_steps = 0.0, 0.0, 4
+                solo_lv = np.zeros(args.levels)
+                # marker in the kernel trace: the solo leg = the k_iter8 dispatches behind the LAST k_stream_read
+                # dispatch (profiles/recompute_roofline.py); also the streaming-read yardstick once more, warm
+                stream_gbps2 = ctypes.c_double(0.0)
+                _lib.check(_lib.load().ictr_stream_read_bandwidth(1 << 30, 2, ctypes.byref(stream_gbps2)))
+                for _ in range(solo_steps):
+                    h0.setpose_all()
+                    h0.track()
+                    h0.poses()
+                    for e_ in h0.engs:
+                        kt_ = e_.kernel_times()
+                        solo_lv += kt_
+                        solo_sum += float(kt_.sum())
+                        solo_first += float(e_.first_iter_times().sum())
+                for e_, st in zip(h0.engs, streams):
+                    e_.set_stream(st.cuda_stream)
+                n_solo = solo_steps * n_eng_step * args.maxiter * args.levels
+                solo = {"t": solo_sum / max(n_solo, 1) * 1e-3, "n": n_solo, "stream_after": stream_gbps2.value,
+                        "regular_us": (solo_sum - solo_first) / max(solo_steps * n_eng_step * (args.maxiter - 1) * args.levels, 1) * 1e3,
+                        "first_us": solo_first / max(solo_steps * n_eng_step * args.levels, 1) * 1e3,
+                        "per_level_us": [float(x) / (solo_steps * n_eng_step * args.maxiter) * 1e3 for x in solo_lv]}
+            t_roof = solo["t"] if solo else t_all
+            if solo:
+                basis = ("un-overlapped: the same engines and launches (same kernels, grids and bytes as the timed steps) "
+                         f"run on ONE stream right after the timed region, mean HIP-event duration of all {solo['n']} "
+                         "k_iter8 launches; reproducible from the rocprofv3 kernel trace of this command "
+                         "(profiles/recompute_roofline.py: mean duration of the k_iter8 dispatches behind the last "
+                         "k_stream_read marker)")
+            elif resident_form:
+                basis = "level launch / maxiter (HIP events around each k_level_resident launch)"
+            else:
+                basis = "mean launch duration (HIP events around each launch; nothing overlaps)"
+            # end to end: ALL algorithmic bytes of a step (16 B per patch pixel and iteration + the level setup's 12 B read
+            # + 12 B written per patch pixel) over the step's wall time -- gaps, tails and host included
+            e2e_bytes = float(B) * args.levels * pix_per_iter * (16.0 * args.maxiter + 24.0)
+            e2e_rate = e2e_bytes / (dt / args.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": alg / t_roof / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": alg / t_roof / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                                "kernel": ("k_level_resident (all iterations of a level in one launch, templates resident "
                                           "on the chip): per iteration = launch / maxiter; its bytes do not cross HBM, so "
                                           "`achieved` is an equivalent rate, not HBM traffic" if resident_form else
-                                          "k_iter8 (GN iteration: steps 7-9a), ALL its launches of the timed steps "
-                                          "(both instantiations: the first launch of a level also sums H)"),
-                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_fair * 1e6,
-                               "launches_timed": n_all,
-                               "duration_basis": ("fair share: every launch is charged the integral of 1 / (kernels in "
-                                                  "flight) over its interval (HIP events of all k_iter8 and setup "
-                                                  "launches of both streams on a common time base)"
-                                                  if overlapping else "mean launch duration (HIP events around each launch)"),
-                               "wall_us_per_launch": t_all * 1e6,
-                               "overlap_factor": (float(ev_kernel.sum()) / busy if (overlapping and busy > 0) else 1.0),
-                               "regular_launch_us": t_kernel * 1e6, "first_iteration_launch_us": t_first * 1e6,
-                               "note": ("two engines of B/2 frame pairs run concurrently on two HIP streams: rocprofv3 "
-                                        "--stats lists the WALL duration of each half-size launch (wall_us_per_launch); "
-                                        "the roofline uses the fair-share duration" if overlapping else None),
+                                          "k_iter8 (GN iteration: steps 7-9a), every launch of every level"),
+                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_roof * 1e6,
+                               "launches_timed": solo["n"] if solo else n_all,
+                               "duration_basis": basis,
+                               "end_to_end": {"algorithmic_bytes_per_step": e2e_bytes, "achieved": e2e_rate,
+                                              "frac": e2e_rate / 8000.0,
+                                              "basis": "frame pairs x levels x patch pixels x (16 B x maxiter + 24 B setup) "
+                                                       "/ ms_per_step / 8 TB/s (per GPU)"},
+                               "fair_share": ({"achieved": alg / t_fair / 1e9, "frac": alg / t_fair / 1e9 / 8000.0,
+                                               "us_per_launch": t_fair * 1e6, "wall_us_per_launch": t_all * 1e6,
+                                               "overlap_factor": float(ev_kernel.sum()) / busy if busy > 0 else 1.0,
+                                               "launches_timed": n_all,
+                                               "basis": "timed region, two engines on two streams: every launch is charged "
+                                                        "the integral of 1 / (kernels in flight) over its interval (HIP "
+                                                        "events of all k_iter8 and setup launches on a common time base); "
+                                                        "wall_us_per_launch is what rocprofv3 --stats averages over the "
+                                                        "overlapped launches"}
+                                              if (overlapping and intervals) else None),
+                               "regular_launch_us": solo["regular_us"] if solo else t_kernel * 1e6,
+                               "first_iteration_launch_us": solo["first_us"] if solo else t_first * 1e6,
                                "measured_stream_read_GBps": stream_gbps.value,
-                               "frac_of_measured_stream_read": alg / t_fair / 1e9 / max(stream_gbps.value, 1e-9),
-                               "per_level_kernel_us": per_level_all,
+                               "measured_stream_read_GBps_after_timed_region": solo["stream_after"] if solo else None,
+                               "frac_of_measured_stream_read": alg / t_roof / 1e9 / max(stream_gbps.value, 1e-9),
+                               "per_level_kernel_us": solo["per_level_us"] if solo else per_level_all,
                                "per_level_bytes_unique_per_px": uniq_bpp,
-                               "per_level_unique_GBps": ([b_ * pix_per_iter * pairs_per_launch / (u * 1e-6) / 1e9 if u > 0 else None
-                                                          for b_, u in zip(uniq_bpp, per_level_all)] if not overlapping else None),
-                               "per_level_regular_kernel_us":
-                                   [float(x - y) / max(args.steps * n_eng_step * (args.maxiter - 1), 1) * 1e3
-                                    for x, y in zip(ev_kernel, ev_first)],
                                "per_level_us_per_iteration_incl_tail_and_gaps":
                                    [float(x) / nl * 1e3 for x in ev_iters] if not sharded else None,
                                "per_level_setup_us":
                                    [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_setup] if not sharded else None}
-            if overlapping and not sharded and streams[0] is not None and not resident_form:
-                # Cross-check without any overlap: the SAME engines and launches (same kernels, same grids: what
-                # rocprofv3 --stats lists under the same names) on ONE stream, so every launch runs alone and its plain
-                # HIP-event duration is the machine time its bytes needed. Not part of the timed region.
-                h0 = holders[0]
-                for e_ in h0.engs:
-                    e_.set_stream(streams[0].cuda_stream)
-                solo_sum, solo_first, solo_steps = 0.0, 0.0, 3
-                for _ in range(solo_steps + 1):
-                    h0.setpose_all()
-                    h0.track()
-                    h0.poses()
-                    if _ == 0:
-                        continue  # warm-up of the single-stream order
-                    for e_ in h0.engs:
-                        solo_sum += float(e_.kernel_times().sum())
-                        solo_first += float(e_.first_iter_times().sum())
-                n_solo = solo_steps * n_eng_step * args.maxiter * args.levels
-                t_solo = solo_sum / max(n_solo, 1) * 1e-3
-                out["roofline"]["solo_check"] = {
-                    "us_per_launch": t_solo * 1e6, "achieved": alg / t_solo / 1e9, "frac": alg / t_solo / 1e9 / 8000.0,
-                    "launches_timed": n_solo,
-                    "regular_launch_us": (solo_sum - solo_first) / max(solo_steps * n_eng_step * (args.maxiter - 1) * args.levels, 1) * 1e3,
-                    "first_iteration_launch_us": solo_first / max(solo_steps * n_eng_step * args.levels, 1) * 1e3,
-                    "basis": "the same engines and launches on ONE stream after the timed region (nothing overlaps): "
-                             "mean HIP-event duration of every k_iter8 launch; comparable to rocprofv3 --stats of "
-                             "`bench.py --streams 1` at half the bytes per launch (profiles/r02_streams1_*)"}
-                for e_, st in zip(h0.engs, streams):
-                    e_.set_stream(st.cuda_stream)
         pose_fail = False
         if args.cpu_seconds > 0 and world == 1 and not sharded:
             # the same tracking on the CPU path (the oracle: checker and baseline, never the product): problem 0 is
@@ -736,7 +777,8 @@ def main():
             holders = tracker = None
             _gc.collect()
             from tools import secondary as sec
-            out["secondary"] = sec.run_all(args.secondary_seconds)
+            out["secondary"] = sec.run_all(args.secondary_seconds,
+                                           cpu_track=cpu_track if args.cpu_seconds > 0 else None)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if pose_fail:

@@ -36,7 +36,8 @@ void launch_project_ref(const EngineDev &, const LevelCam *, int, hipStream_t);
 void launch_ref_level(const EngineDev &, const LevelCam &, int, int, int, int, int, hipStream_t);
 void launch_level_finish(const EngineDev &, int, hipStream_t);
 void launch_iter(const EngineDev &, const LevelCam &, int, int, int, int, int, int, hipStream_t);
-void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, int, int, hipStream_t);
+void launch_iter_main(const EngineDev &, const LevelCam &, int, int, int, int, int, int, hipStream_t, hipEvent_t,
+                      hipEvent_t);
 void launch_iter_tail(const EngineDev &, int, int, int, int, int, hipStream_t);
 void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
@@ -1185,13 +1186,11 @@ extern "C" int ictr_batch_iter_accumulate(ictr_batch *b, int level) {
   const bool tk = b->timing && b->phase_it < b->evk_iters && (int)b->evk.size() >= 2 * b->nlev * b->evk_iters;
   const EngineDev e = engine_dev(b);
   const LevelCam lc = level_cam(b->cam, level);
-  if (tk) HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it)], b->stream));
   const int first = b->phase_it == 0;
-  launch_iter_main(e, lc, level, b->gridx, engine_variant(b), b->cpw, b->gridx8, first, b->stream);
-  if (tk) {
-    HIPCHK(hipEventRecord(b->evk[2 * (level * b->evk_iters + b->phase_it) + 1], b->stream));
-    if (b->phase_it + 1 == std::min(b->op->maxiter, b->evk_iters)) b->ev_used[level] = 2;  // kernel events complete
-  }
+  const int ke = 2 * (level * b->evk_iters + b->phase_it);
+  launch_iter_main(e, lc, level, b->gridx, engine_variant(b), b->cpw, b->gridx8, first, b->stream,
+                   tk ? b->evk[ke] : nullptr, tk ? b->evk[ke + 1] : nullptr);
+  if (tk && b->phase_it + 1 == std::min(b->op->maxiter, b->evk_iters)) b->ev_used[level] = 2;  // kernel events complete
   b->phase_it++;
   launch_iter_tail(e, level, b->gridx, engine_variant(b), b->gridx8, first, b->stream);
   HIPCHK(hipGetLastError());
@@ -1510,7 +1509,7 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
       const LevelCam lc = level_cam(b->cam, sl);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
-      launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 22) | (1 << 24), b->cpw, b->gridx8, s);
+      launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 24), b->cpw, b->gridx8, s);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
       if (int rc = launch_resident(b, e, lc, sl, rp, s)) return rc;
       if (events) {
@@ -1530,9 +1529,9 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     launch_ref_level(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, s);
     if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
     for (int it = 0; it < mi; ++it) {
-      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it)], s));
-      launch_iter_main(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, it == 0, s);
-      if (tk) HIPCHK(hipEventRecord(b->evk[2 * (sl * b->evk_iters + it) + 1], s));
+      const int ke = 2 * (sl * b->evk_iters + it);
+      launch_iter_main(e, lc, sl, b->gridx, engine_variant(b), b->cpw, b->gridx8, it == 0, s,
+                       tk ? b->evk[ke] : nullptr, tk ? b->evk[ke + 1] : nullptr);
       launch_iter_tail(e, sl, b->gridx, engine_variant(b), b->gridx8, it == 0, s);
     }
     if (events) {

@@ -26,6 +26,8 @@
 // order of the big sums differs.
 #include <algorithm>
 
+#include <hip/hip_ext.h>
+
 #include "ictr_dev.h"
 #include "ictr_devfn.h"
 #include "se3_math.h"
@@ -487,29 +489,24 @@ __device__ __forceinline__ float taps_blend4(const TapLoads4 &t, int k, float w0
 template <int kU>
 struct PatchLoads {  // raw load results of one stage-2 step of kU patches (consumers belong to the reduce phase)
   float t[kU], gx[kU], gy[kU];
-  TapLoads cur[kU];  // LD == 2: .ab = (x-1,y),(x,y) and .top = (x-1,y-1),(x,y-1) of the lane's own pixel
-  int rec[kU];  // LDS record index of the patch, or -1 for the padding of a partial step
+  TapLoads cur[kU];  // .ab = (x-1,y),(x,y) and .top = (x-1,y-1),(x,y-1) of the lane's own pixel
+  int rec[kU];       // LDS record index of the patch, or 64 (the zero record) for the padding of a partial step
 };
 
-// LD selects how stage 2 addresses memory (same bytes, same values):
-//   0  global loads (scalar base + per-lane 64-bit address arithmetic), window rows de-duplicated: own row pair per
-//      lane, the row above for lanes 0-7 only, everyone else by ds_bpermute from the lane one row up (round 1);
-//   1  the same loads as buffer loads: plane / patch-buffer descriptor in SGPRs, wave-uniform offset in an SGPR,
-//      per-lane constant byte offset in a VGPR -> no vector address arithmetic per load;
-//   2  buffer loads, and every lane loads its own two row pairs (x-1,x at y and y-1): no cross-lane traffic, no
-//      selects; neighbouring lanes' requests hit the same cache lines;
-//   3  as 2 with the per-patch bookkeeping cut down (the form k_track1_p8's patch loop took, ictr_track1.hip): the
-//      LDS record is [w1 w0 w3 w2][cx2..5][cy2..5][cx0 cy1 vis -] -- four ds_read_b128 at one address, operands already
-//      paired for the packed multiply-adds, no re-pairing moves; the window's byte offset is computed per POINT in
-//      stage 1 (one v_readlane per patch, no scalar arithmetic behind it); the padding of a partial pipeline step
-//      points at a zero record (an exact zero contribution to b and to H) instead of being branched around.
+// Stage-2 addressing (what survived round 2's A/B runs, profiles/r02_notes.md): buffer loads -- plane / patch-buffer
+// descriptor in SGPRs, wave-uniform offset in an SGPR, per-lane constant byte offset in a VGPR, no vector address
+// arithmetic per load; every lane loads its own two row pairs (x-1,x at y and y-1): no cross-lane traffic, no selects,
+// neighbouring lanes' requests hit the same cache lines. The LDS record of a point is
+// [w1 w0 w3 w2][cx2..5][cy2..5][cx0 cy1 vis -]: four ds_read_b128 at one address, operands already paired for the packed
+// multiply-adds; the window's byte offset is computed per POINT in stage 1 (one v_readlane per patch); the padding of a
+// partial pipeline step points at a zero record (an exact zero contribution to b) instead of being branched around.
 // A wave issues at most one instruction of any kind per ~4 cycles, so at the coarse levels (frames cached) the
-// kernel's pace is its instruction count per patch, not bytes (profiles/r02_notes.md).
-template <bool PN, int kU, bool NT = true, bool WH = false, int LD = 0>  // WH: also accumulate the 21 H sums
+// kernel's pace is its instruction count per patch, not bytes.
+// (H is no longer summed here: the setup kernel k_ref8 leaves the level's H partials, from three sums per patch.)
+template <bool PN, int kU>
 __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int level, int cpw) {
-  __shared__ __attribute__((aligned(16))) float sRec[kWaves][65 * kRec];  // record 64: zeros (LD == 3)
+  __shared__ __attribute__((aligned(16))) float sRec[kWaves][65 * kRec];  // record 64: zeros
   __shared__ float sW[kWaves][kPartBStride];
-  __shared__ float sWH[WH ? kWaves : 1][kPartHStride];
   const int b = blockIdx.y;
   const ProbState &st = e.st[b];
   if (!st.active) return;
@@ -521,9 +518,8 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
   const float *__restrict__ Gx = e.Gx + (size_t)b * M * 64;
   const float *__restrict__ Gy = e.Gy + (size_t)b * M * 64;
   const float *__restrict__ coefb = e.coef + (size_t)b * M * kCoefStride;
-  gconst_f32 cur = (gconst_f32)pl.cur;
   const int sw = lc.sw;
-  // LD >= 1: buffer descriptors (base, no stride, max range, raw dword format) of the current frame and the patches
+  // buffer descriptors (base, no stride, max range, raw dword format) of the current frame and the patches
   const __amdgpu_buffer_rsrc_t rcur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl.cur), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rGx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Gx), 0, 0x7fffffff, 0x00020000);
@@ -535,20 +531,11 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int loff = (lane >> 3) * sw + (lane & 7);
   float *rec = sRec[wave];
   const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
-  if constexpr (LD == 3) {
-    if (lane < kRec) rec[64 * kRec + lane] = 0.0f;  // (first read behind stage 1's wave barrier)
-  }
+  if (lane < kRec) rec[64 * kRec + lane] = 0.0f;  // (first read behind stage 1's wave barrier)
 
-  float acc[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) acc[k] = 0.0f;
-  f32x2_t acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}, acc45 = {0.0f, 0.0f};  // LD == 3: the same six sums as pairs
-  float accH[WH ? kHUnique : 1];
-#pragma unroll
-  for (int j = 0; j < (WH ? kHUnique : 1); ++j) accH[j] = 0.0f;
+  f32x2_t acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}, acc45 = {0.0f, 0.0f};  // the six J^T r sums as register pairs
 
   const int nchunks = (npts + cpw - 1) / cpw;
   for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
@@ -568,20 +555,13 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
     const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
     const int base_v = tp.row0 * sw + tp.col0;
-    const int so_v = (base_v - sw - 1) * 4;  // LD == 3: bytes to the window's top-left texel (tap d of pixel 0)
-    if constexpr (LD == 3) {
+    const int so_v = (base_v - sw - 1) * 4;  // bytes to the window's top-left texel (tap d of pixel 0)
+    {
       float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
       r4[0] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
       r4[1] = make_float4(q0.z, q0.w, q1.x, q1.y);  // cx2 cx3 cx4 cx5
       r4[2] = make_float4(q2.x, q2.y, q2.z, q2.w);  // cy2 cy3 cy4 cy5
       r4[3] = make_float4(q0.x, q1.w, vis ? 1.0f : 0.0f, 0.0f);  // cx0 cy1 vis -
-    } else {
-      float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
-      r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
-      // [cx0 cy1 | cx2 cx3][cy2 cy3 | cx4 cx5][cy4 cy5 | vis -]: operand pairs of the packed multiply-adds below
-      r4[1] = make_float4(q0.x, q1.w, q0.z, q0.w);
-      r4[2] = make_float4(q2.x, q2.y, q1.x, q1.y);
-      r4[3] = make_float4(q2.z, q2.w, vis ? 1.0f : 0.0f, 0.0f);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -594,121 +574,41 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
       for (int u = 0; u < kU; ++u) {
         const int jraw = sidx + u * nsteps;
         const int jj = min(jraw, cnt - 1);
-        if constexpr (LD == 3) {
-          constexpr int aux = NT ? 2 : 0;
-          L.rec[u] = (jraw < cnt) ? jj : 64;  // padding: the zero record; its loads repeat the chunk's last patch
-          const int so = rlane(so_v, jj);
-          const int po4 = (i0 + jj) * 256;
-          const int off_cd = ((lane >> 3) * sw + (lane & 7)) * 4, off_ab = off_cd + sw * 4;
-          L.t[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, lane * 4, po4, aux));
-          L.gx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, lane * 4, po4, aux));
-          L.gy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, lane * 4, po4, aux));
-          L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_ab, so, 0));
-          L.cur[u].top = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_cd, so, 0));
-          continue;
-        }
-        L.rec[u] = (jraw < cnt) ? jj : -1;
-        const int base = rlane(base_v, jj);
-        if constexpr (LD == 0) {
-          const size_t po = (size_t)(i0 + jj) * 64;  // wave-uniform: scalar base + 32-bit lane offset
-          if constexpr (NT) {  // streamed once per launch: keep them from evicting the (re-used) frame lines
-            L.t[u] = __builtin_nontemporal_load(T + po + lane);
-            L.gx[u] = __builtin_nontemporal_load(Gx + po + lane);
-            L.gy[u] = __builtin_nontemporal_load(Gy + po + lane);
-          } else {
-            L.t[u] = (T + po)[lane];
-            L.gx[u] = (Gx + po)[lane];
-            L.gy[u] = (Gy + po)[lane];
-          }
-          L.cur[u] = taps_issue(cur + base, loff, sw, lane);
-        } else {
-          constexpr int aux = NT ? 2 : 0;  // gfx950 cache policy bits of a buffer load: bit 1 = nt
-          const int po4 = (i0 + jj) * 256;  // bytes: one 8x8 float patch = 256 B
-          L.t[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, lane * 4, po4, aux));
-          L.gx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, lane * 4, po4, aux));
-          L.gy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, lane * 4, po4, aux));
-          const int so = (base - sw - 1) * 4;  // bytes: the window's top-left texel (tap d of pixel 0)
-          const int off_cd = ((lane >> 3) * sw + (lane & 7)) * 4, off_ab = off_cd + sw * 4;
-          L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_ab, so, 0));
-          f32x2_a4 q = {0.0f, 0.0f};
-          if (LD == 2 || lane < 8) q = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_cd, so, 0));
-          L.cur[u].top = q;
-        }
+        constexpr int aux = 2;  // gfx950 cache policy bits of a buffer load: bit 1 = nt (streamed once per launch:
+                                // keep them from evicting the re-used frame lines)
+        L.rec[u] = (jraw < cnt) ? jj : 64;  // padding: the zero record; its loads repeat the chunk's last patch
+        const int so = rlane(so_v, jj);
+        const int po4 = (i0 + jj) * 256;  // bytes: one 8x8 float patch = 256 B
+        const int off_cd = ((lane >> 3) * sw + (lane & 7)) * 4, off_ab = off_cd + sw * 4;
+        L.t[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, lane * 4, po4, aux));
+        L.gx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, lane * 4, po4, aux));
+        L.gy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, lane * 4, po4, aux));
+        L.cur[u].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_ab, so, 0));
+        L.cur[u].top = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, off_cd, so, 0));
       }
     };
     auto reduce = [&](const PatchLoads<kU> &L) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        if constexpr (LD == 3) {
-          // (compiler barrier tied to the accumulators: keeps the four record reads of patch u behind the sums of patch
-          // u - 1 -- hoisted together they cost 64 registers and two waves of occupancy)
-          asm volatile("" : "+v"(acc01), "+v"(acc23), "+v"(acc45) : : "memory");
-          const float4 *r4 = rec4 + L.rec[u] * 4;
-          const float4 wv = r4[0], qx = r4[1], qy = r4[2], qz = r4[3];
-          // utilities.cpp:107 in the reference's operand order, never contracted: ((w0 a + w1 b) + w2 c) + w3 d
-          float inew = wv.y * L.cur[u].ab.y + wv.x * L.cur[u].ab.x + wv.w * L.cur[u].top.y + wv.z * L.cur[u].top.x;
-          if constexpr (PN) inew -= wave_sum(inew) / 64.0f;  // utilities.cpp:111-112
-          const float gx = L.gx[u], gy = L.gy[u];
-          const float r = (L.t[u] - inew) * qz.z;  // pdiff (odometer.cpp:381); 0 out of view and for padding
-          // the J^T r (and H) sums are compared to tolerance only: explicit multiply-adds
-          // (as register PAIRS: v_pk_fma_f32 does two of the six sums per instruction)
-          const f32x2_t g2 = {gx * r, gy * r}, gr2 = {g2.x, g2.x}, hr2 = {g2.y, g2.y};
-          acc01 = __builtin_elementwise_fma(g2, (f32x2_t){qz.x, qz.y}, acc01);  // sd1 = Gx cx0, sd2 = Gy cy1
-          acc23 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.x, qx.y},         // sd3..sd6 = Gx cxk + Gy cyk
-                                            __builtin_elementwise_fma(hr2, (f32x2_t){qy.x, qy.y}, acc23));
-          acc45 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.z, qx.w},         // (odometer.cpp:319-326)
-                                            __builtin_elementwise_fma(hr2, (f32x2_t){qy.z, qy.w}, acc45));
-          if constexpr (WH) {  // H = sum sd_j sd_k over every stored patch, visible or stale (odometer.cpp:428-455);
-            float sd[6];       // the padding record's coefficients are zero: an exact zero contribution
-            sd[0] = gx * qz.x;
-            sd[1] = gy * qz.y;
-            sd[2] = __builtin_fmaf(gx, qx.x, gy * qy.x);
-            sd[3] = __builtin_fmaf(gx, qx.y, gy * qy.y);
-            sd[4] = __builtin_fmaf(gx, qx.z, gy * qy.z);
-            sd[5] = __builtin_fmaf(gx, qx.w, gy * qy.w);
-            int jk = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-              for (int c = a; c < 6; ++c, ++jk) accH[jk] = __builtin_fmaf(sd[a], sd[c], accH[jk]);
-          }
-          continue;
-        }
-        if (L.rec[u] < 0) continue;  // wave-uniform
-        const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
-                     k2 = rec4[L.rec[u] * 4 + 3];
-        float inew;
-        if constexpr (LD == 2)  // utilities.cpp:107 in the reference's operand order, never contracted (see taps_blend)
-          inew = w.x * L.cur[u].ab.y + w.y * L.cur[u].ab.x + w.z * L.cur[u].top.y + w.w * L.cur[u].top.x;
-        else
-          inew = taps_blend(L.cur[u], w.x, w.y, w.z, w.w, lane);
+        // (compiler barrier tied to the accumulators: keeps the four record reads of patch u behind the sums of patch
+        // u - 1 -- hoisted together they cost 64 registers and two waves of occupancy)
+        asm volatile("" : "+v"(acc01), "+v"(acc23), "+v"(acc45) : : "memory");
+        const float4 *r4 = rec4 + L.rec[u] * 4;
+        const float4 wv = r4[0], qx = r4[1], qy = r4[2], qz = r4[3];
+        // utilities.cpp:107 in the reference's operand order, never contracted: ((w0 a + w1 b) + w2 c) + w3 d -- template
+        // and current patch must round identically so that identical frames give a residual of exactly zero
+        float inew = wv.y * L.cur[u].ab.y + wv.x * L.cur[u].ab.x + wv.w * L.cur[u].top.y + wv.z * L.cur[u].top.x;
         if constexpr (PN) inew -= wave_sum(inew) / 64.0f;  // utilities.cpp:111-112
-        const float tv = L.t[u], gx = L.gx[u], gy = L.gy[u];
-        const float r = (tv - inew) * k2.z;  // pdiff (odometer.cpp:381); k2.z = 0 for points out of view
-        {
-#pragma clang fp contract(fast)  // the J^T r sums are compared to tolerance only: FMA allowed from here on
-          const float gr = gx * r, hr = gy * r;
-          acc[0] += gr * k0.x;                // sd1 = Gx cx0
-          acc[1] += hr * k0.y;                // sd2 = Gy cy1
-          acc[2] += gr * k0.z + hr * k1.x;    // sd3..sd6 = Gx cxk + Gy cyk (odometer.cpp:319-326)
-          acc[3] += gr * k0.w + hr * k1.y;
-          acc[4] += gr * k1.z + hr * k2.x;
-          acc[5] += gr * k1.w + hr * k2.y;
-          if constexpr (WH) {  // H = sum sd_j sd_k over every stored patch, visible or stale (odometer.cpp:428-455)
-            float sd[6];
-            sd[0] = gx * k0.x;
-            sd[1] = gy * k0.y;
-            sd[2] = gx * k0.z + gy * k1.x;
-            sd[3] = gx * k0.w + gy * k1.y;
-            sd[4] = gx * k1.z + gy * k2.x;
-            sd[5] = gx * k1.w + gy * k2.y;
-            int jk = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-              for (int c = a; c < 6; ++c) accH[jk++] += sd[a] * sd[c];
-          }
-        }
+        const float gx = L.gx[u], gy = L.gy[u];
+        const float r = (L.t[u] - inew) * qz.z;  // pdiff (odometer.cpp:381); 0 out of view and for padding
+        // the J^T r sums are compared to tolerance only: explicit multiply-adds
+        // (as register PAIRS: v_pk_fma_f32 does two of the six sums per instruction)
+        const f32x2_t g2 = {gx * r, gy * r}, gr2 = {g2.x, g2.x}, hr2 = {g2.y, g2.y};
+        acc01 = __builtin_elementwise_fma(g2, (f32x2_t){qz.x, qz.y}, acc01);  // sd1 = Gx cx0, sd2 = Gy cy1
+        acc23 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.x, qx.y},         // sd3..sd6 = Gx cxk + Gy cyk
+                                          __builtin_elementwise_fma(hr2, (f32x2_t){qy.x, qy.y}, acc23));
+        acc45 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.z, qx.w},         // (odometer.cpp:319-326)
+                                          __builtin_elementwise_fma(hr2, (f32x2_t){qy.z, qy.w}, acc45));
       }
     };
     PatchLoads<kU> A, B;
@@ -723,9 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     __builtin_amdgcn_wave_barrier();  // the records are rewritten by the next chunk
   }
 
-  if constexpr (LD == 3) {
-    acc[0] = acc01.x, acc[1] = acc01.y, acc[2] = acc23.x, acc[3] = acc23.y, acc[4] = acc45.x, acc[5] = acc45.y;
-  }
+  const float acc[6] = {acc01.x, acc01.y, acc23.x, acc23.y, acc45.x, acc45.y};
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const float v = wave_sum(acc[k]);
@@ -736,39 +634,27 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
     const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
     e.partb[((size_t)b * gridDim.x + blockIdx.x) * kPartBStride + threadIdx.x] = v;
   }
-  if constexpr (WH) {
-#pragma unroll
-    for (int j = 0; j < kHUnique; ++j) {
-      const float v = wave_sum(accH[j]);
-      if (lane == 0) sWH[wave][j] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kHUnique) {
-      const float v = (sWH[0][threadIdx.x] + sWH[1][threadIdx.x]) + (sWH[2][threadIdx.x] + sWH[3][threadIdx.x]);
-      e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
-    }
-  }
 }
 
-// steps 4-6 for 8x8 patches, same two-stage, software-pipelined form (reference patches + gradients, sd
-// coefficients, H partials). The patches T/Gx/Gy it stores are bit-exact (un-contracted blends); only the 21 H sums,
-// which are compared to tolerance, use FMA.
+// steps 4-6 for 8x8 patches, same two-stage, software-pipelined form: reference patches + gradients (bit-exact:
+// un-contracted blends), sd coefficients, and the level's H partials in the form SURVEY.md §8 a18 prescribes. The
+// steepest-descent images are sd_k = Gx cx_k + Gy cy_k with per-POINT constants cx, cy (odometer.cpp:313-326), so
+//   H_jk = sum_pixels sd_j sd_k (odometer.cpp:428-455) = sum_points [cx_j cx_k Sxx + (cx_j cy_k + cy_j cx_k) Sxy + cy_j cy_k Syy]
+// with three sums per patch, Sxx = sum Gx^2, Sxy = sum Gx Gy, Syy = sum Gy^2 (wave reductions while the kernel waits on
+// memory anyway), instead of 21 multiply-adds per pixel in a separate instantiation of the iteration kernel. A point out
+// of the reference view keeps its stale patch and coefficients (odometer.cpp:304): its S is summed from the stored
+// gradients, so nothing but the patch buffers and the coefficient line carries state from level to level.
+// H is compared to tolerance only (summation order differs from the CPU path's whole-buffer sums anyway).
 template <int kU>
 struct RefLoads {
   TapLoads r[kU], x[kU], y[kU];
   TapLoads4 p4[kU];
-  float sgx[kU], sgy[kU];  // stale gradients of a patch that is out of the reference view at this level
   int rec[kU];
   int vis[kU];
 };
 
-// (Buffer addressing as in k_iter8 was measured here too, r02: 414/395/340 us per level with the round-1 addressing,
-// 441/405/346 with buffer loads + row-up shuffles, 429/399/336 with per-lane texel loads: noise. This kernel waits on
-// memory, not on instruction issue; the round-1 form stays.)
-template <bool PN, int kU, bool NT = true, bool WH = true, bool PK = false>  // WH = false: H deferred; PK: packed planes
-__global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw, int dbg) {
-  // dbg (variant bits 9-11, ablation experiments only, results wrong on purpose): 1 no stores, 2 one plane's taps
-  // used for all three, 4 no tap loads at all
+template <bool PN, int kU, bool PK>  // PK: packed {img, dx, dy, 0} reference planes
+__global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartHStride];
   const int b = blockIdx.y;
@@ -792,9 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   float *rec = sRec[wave];
   const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
 
-  float acc[WH ? kHUnique : 1];
-#pragma unroll
-  for (int j = 0; j < (WH ? kHUnique : 1); ++j) acc[j] = 0.0f;
+  float accH = 0.0f;  // lane j < 21: the wave's sum of H entry j (upper triangle, row-major)
 
   const int nchunks = (npts + cpw - 1) / cpw;
   for (int ch = xcd_band_block(blockIdx.x, gridDim.x) * kWaves + wave; ch < nchunks; ch += gridDim.x * kWaves) {
@@ -823,15 +707,16 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     {
       float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
       r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
-      r4[1] = make_float4(cx[0], cx[2], cx[3], cx[4]);
-      r4[2] = make_float4(cx[5], cy[1], cy[2], cy[3]);
-      r4[3] = make_float4(cy[4], cy[5], 0.0f, 0.0f);
+      r4[1] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+      r4[2] = make_float4(cx[4], cx[5], cy[0], cy[1]);
+      r4[3] = make_float4(cy[2], cy[3], cy[4], cy[5]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- stage 2 (utilities.cpp:115-189, odometer.cpp:428-455); patches of a step are nsteps apart
+    // ---- stage 2 (utilities.cpp:115-189); patches of a step are nsteps apart
+    float sxx_v = 0.0f, sxy_v = 0.0f, syy_v = 0.0f;  // lane j: S of the chunk's point j (0 beyond the chunk)
     const int nsteps = (cnt + kU - 1) / kU;
     auto issue = [&](RefLoads<kU> &L, int sidx) {
 #pragma unroll
@@ -844,33 +729,28 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         if (L.vis[u]) {  // wave-uniform
           if constexpr (PK) {
             L.p4[u] = taps_issue4(ppack + base, loff, sw, lane);
-          } else if (dbg & 4) {
-            L.r[u].ab = L.r[u].top = f32x2_a4{1.0f, 2.0f};
-            L.x[u] = L.y[u] = L.r[u];
           } else {
             L.r[u] = taps_issue(pref + base, loff, sw, lane);
-            if (dbg & 2) {
-              L.x[u] = L.y[u] = L.r[u];
-            } else {
-              L.x[u] = taps_issue(pdx + base, loff, sw, lane);
-              L.y[u] = taps_issue(pdy + base, loff, sw, lane);
-            }
+            L.x[u] = taps_issue(pdx + base, loff, sw, lane);
+            L.y[u] = taps_issue(pdy + base, loff, sw, lane);
           }
-        } else if constexpr (WH) {
-          const size_t po = (size_t)(i0 + jj) * 64;
-          L.sgx[u] = (Gx + po)[lane];
-          L.sgy[u] = (Gy + po)[lane];
         }
       }
+    };
+    auto patch_sums = [&](float gx, float gy, int j) {  // the patch's three sums into lane j (the sums are wave-uniform)
+      const float sxx = wave_sum_dpp(gx * gx), sxy = wave_sum_dpp(gx * gy), syy = wave_sum_dpp(gy * gy);
+      const bool mine = lane == j;
+      sxx_v = mine ? sxx : sxx_v;
+      sxy_v = mine ? sxy : sxy_v;
+      syy_v = mine ? syy : syy_v;
     };
     auto reduce = [&](const RefLoads<kU> &L) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        if (L.rec[u] < 0) continue;  // wave-uniform
-        const float4 w = rec4[L.rec[u] * 4 + 0], k0 = rec4[L.rec[u] * 4 + 1], k1 = rec4[L.rec[u] * 4 + 2],
-                     k2 = rec4[L.rec[u] * 4 + 3];
+        if (L.rec[u] < 0 || !L.vis[u]) continue;  // wave-uniform
         float gx, gy;
-        if (L.vis[u]) {
+        {
+          const float4 w = rec4[L.rec[u] * 4 + 0];
           float t;
           if constexpr (PK) {
             t = taps_blend4(L.p4[u], 0, w.x, w.y, w.z, w.w, lane);
@@ -883,36 +763,12 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
           }
           if constexpr (PN) t -= wave_sum(t) / 64.0f;  // utilities.cpp:187-188
           const size_t po = (size_t)(i0 + L.rec[u]) * 64;
-          if (dbg & 1) {
-            if (t + gx + gy == 1.2345e30f) T[po + lane] = t;  // keep the values alive
-          } else if constexpr (NT) {  // 400 MB written once per level: do not let them push the pyramid planes out of L2
-            __builtin_nontemporal_store(t, T + po + lane);
-            __builtin_nontemporal_store(gx, Gx + po + lane);
-            __builtin_nontemporal_store(gy, Gy + po + lane);
-          } else {
-            (T + po)[lane] = t;
-            (Gx + po)[lane] = gx;
-            (Gy + po)[lane] = gy;
-          }
-        } else if constexpr (WH) {
-          gx = L.sgx[u];
-          gy = L.sgy[u];
+          // 400 MB written once per level: do not let them push the pyramid planes out of L2
+          __builtin_nontemporal_store(t, T + po + lane);
+          __builtin_nontemporal_store(gx, Gx + po + lane);
+          __builtin_nontemporal_store(gy, Gy + po + lane);
         }
-        if constexpr (WH) {
-#pragma clang fp contract(fast)  // H = sum sd_j sd_k is compared to tolerance only
-          float sd[6];
-          sd[0] = gx * k0.x;
-          sd[1] = gy * k1.y;
-          sd[2] = gx * k0.y + gy * k1.z;
-          sd[3] = gx * k0.z + gy * k1.w;
-          sd[4] = gx * k0.w + gy * k2.x;
-          sd[5] = gx * k1.x + gy * k2.y;
-          int jk = 0;
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = a; c < 6; ++c) acc[jk++] += sd[a] * sd[c];
-        }
+        patch_sums(gx, gy, L.rec[u]);
       }
     };
     RefLoads<kU> A, B;
@@ -923,21 +779,41 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
       if (sidx + 2 < nsteps) issue(A, sidx + 2);
       if (sidx + 1 < nsteps) reduce(B);
     }
+    // points out of the reference view at this level (rare): S of the stale patch, from the stored gradients
+    for (unsigned long long stale = __builtin_amdgcn_ballot_w64(pv && !vis); stale; stale &= stale - 1) {
+      const int j = __builtin_ctzll(stale);
+      const size_t po = (size_t)(i0 + j) * 64;
+      patch_sums((Gx + po)[lane], (Gy + po)[lane], j);
+    }
+    // ---- H += J^T S J, one point per lane again (its coefficients come back from the wave's records)
+    {
+      const float4 k0 = rec4[lane * 4 + 1], k1 = rec4[lane * 4 + 2], k2 = rec4[lane * 4 + 3];
+      const float ax[6] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y}, ay[6] = {k1.z, k1.w, k2.x, k2.y, k2.z, k2.w};
+      float uj[6], vj[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        uj[j] = __builtin_fmaf(ax[j], sxx_v, ay[j] * sxy_v);
+        vj[j] = __builtin_fmaf(ax[j], sxy_v, ay[j] * syy_v);
+      }
+      int jk = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int k = j; k < 6; ++k, ++jk) {
+          const float h = wave_sum_dpp(__builtin_fmaf(ax[k], uj[j], ay[k] * vj[j]));
+          accH += lane == jk ? h : 0.0f;
+          if (jk % 3 == 2) asm volatile("" : "+v"(accH));  // three reductions at a time (their row sums sit in SGPRs)
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 
-  if constexpr (WH) {
-#pragma unroll
-    for (int j = 0; j < kHUnique; ++j) {
-      const float v = wave_sum(acc[j]);
-      if (lane == 0) sW[wave][j] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kHUnique) {
-      const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
-      e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
-    }
+  if (lane < kPartHStride) sW[wave][lane] = lane < kHUnique ? accH : 0.0f;
+  __syncthreads();
+  if (threadIdx.x < kHUnique) {
+    const float v = (sW[0][threadIdx.x] + sW[1][threadIdx.x]) + (sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+    e.partH[((size_t)b * gridDim.x + blockIdx.x) * kPartHStride + threadIdx.x] = v;
   }
 }
 
@@ -1618,9 +1494,11 @@ void launch_project_ref(const EngineDev &e, const LevelCam *cams, int maxpts, hi
   for (int l = 0; l < e.nlev && l < 16; ++l) ac.lc[l] = cams[l];
   hipLaunchKernelGGL(k_project_ref, dim3((maxpts + kBlock - 1) / kBlock, e.B), dim3(kBlock), 0, s, e, ac);
 }
-// Deferred H (P = 8 fast path, default): the setup kernel only gathers and stores the patches; the 21 H sums are
-// accumulated by the level's first iteration launch, which streams Gx, Gy and the coefficients anyway. Variant bit 8
-// (256) keeps H in the setup kernel (the previous form, kept for A/B and as a cross-check in the tests).
+// Deferred H: on the wave64 fast paths the level's H partials are reduced and factored by the level's FIRST iteration
+// tail (k_iter_tail / k_iter_finish with first_h), not by k_level_tail -- in sharded mode H then travels in the same
+// 27-float message as the first b and the level phase needs no collective of its own. Where the partials come from:
+// P = 8: the setup kernel k_ref8 (three sums per patch, H = sum J^T S J); P = 4: the first k_iter4<.., WH> launch.
+// Variant bit 8 (256) lets k_level_tail reduce and factor H for P = 8 (cross-check in the tests).
 // wave64 fast paths: 8x8 always, 4x4 when every reference pyramid carries the packed planes
 static bool fast8(const EngineDev &e, int variant) { return e.P == 8 && !(variant & 2); }
 static bool fast4(const EngineDev &e, int variant) { return e.P == 4 && e.packed && !(variant & 2); }
@@ -1633,45 +1511,20 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
   const dim3 blk(kBlock);
   int nblk = gridx;
   const bool dh = defer_h(e, variant);
-  if (e.P == 8 && !(variant & 2)) {
+  if (fast8(e, variant)) {
     nblk = gridx8;
     const dim3 g8(gridx8, e.B);
-    const int ku = (variant >> 6) & 3;  // experiments: patches per pipeline step of the setup kernel
-    const int dbg = (variant >> 9) & 7;
     const bool pk = e.packed && !(variant & 4096);  // variant bit 12: three separate planes (A/B)
-    if (dh && pk) {
-      if (e.dopatchnorm)
-        hipLaunchKernelGGL((k_ref8<true, 1, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else if (ku == 2)
-        hipLaunchKernelGGL((k_ref8<false, 1, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else if (ku == 3)
-        hipLaunchKernelGGL((k_ref8<false, 4, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else  // default: two patches per pipeline step (measured: 1 -> 2 saves 50-120 us per level, 4 adds nothing)
-        hipLaunchKernelGGL((k_ref8<false, 2, true, false, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-    } else if (dh) {
-      if (e.dopatchnorm)
-        hipLaunchKernelGGL((k_ref8<true, 1, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else if (ku == 1)
-        hipLaunchKernelGGL((k_ref8<false, 2, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else if (ku == 3)
-        hipLaunchKernelGGL((k_ref8<false, 4, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else
-        hipLaunchKernelGGL((k_ref8<false, 1, true, false>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-    } else if (pk && !e.dopatchnorm && (variant & (1 << 22))) {
-      // H summed by the setup kernel itself, from the packed planes (the resident-iteration form, ictr_resident.hip,
-      // has no H-accumulating first iteration launch); variant bits 6-7 = 2: one patch per pipeline step
-      if (ku == 2)
-        hipLaunchKernelGGL((k_ref8<false, 1, true, true, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-      else
-        hipLaunchKernelGGL((k_ref8<false, 2, true, true, true>), g8, blk, 0, s, e, lc, level, cpw, dbg);
-    } else if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_ref8<true, 1>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
-    else if (ku == 1)
-      hipLaunchKernelGGL((k_ref8<false, 2>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
-    else if (ku == 2)
-      hipLaunchKernelGGL((k_ref8<false, 1, false>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);  // A/B: temporal stores
+    // patches per pipeline step: two with the packed planes (measured r02: 1 -> 2 saves 50-120 us per level, 4 adds
+    // nothing), one otherwise
+    if (pk && e.dopatchnorm)
+      hipLaunchKernelGGL((k_ref8<true, 1, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (pk)
+      hipLaunchKernelGGL((k_ref8<false, 2, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (e.dopatchnorm)
+      hipLaunchKernelGGL((k_ref8<true, 1, false>), g8, blk, 0, s, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL((k_ref8<false, 1>), g8, blk, 0, s, e, lc, level, cpw, (variant >> 9) & 7);
+      hipLaunchKernelGGL((k_ref8<false, 1, false>), g8, blk, 0, s, e, lc, level, cpw);
   } else if (fast4(e, variant)) {
     nblk = gridx8;
     if (e.dopatchnorm)
@@ -1682,79 +1535,53 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
     hipLaunchKernelGGL(k_ref_level<4>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
   else
     hipLaunchKernelGGL(k_ref_level<0>, dim3(gridx, e.B), blk, 0, s, e, lc, level);
-  // (the resident-iteration launch that follows reduces and factors H itself: its solver workgroups are idle while the
-  // workers load their templates)
-  if (!(fast8(e, variant) && (variant & (1 << 24)) && (variant & (1 << 22)) && !dh && e.packed && !e.dopatchnorm &&
-        !(variant & 4096)))  // bit 24: set by the host's resident path only
+  // variant bit 24 (set by the host's resident path only): no tail -- the resident-iteration launch that follows reduces
+  // and factors H itself (its solver workgroups are idle while the workers load their templates)
+  if (!(fast8(e, variant) && (variant & (1 << 24))))
     hipLaunchKernelGGL(k_level_tail, dim3(e.B), blk, 0, s, e, nblk, dh ? 1 : 0);
 }
 void launch_level_finish(const EngineDev &e, int variant, hipStream_t s) {
   hipLaunchKernelGGL(k_level_finish, dim3(e.B), dim3(64), 0, s, e, defer_h(e, variant) ? 1 : 0);
 }
 // steps 7-9a of one Gauss-Newton iteration for every problem (the accumulate kernel) ...
-// first: the level's first iteration (with deferred H it also accumulates the H partials)
+// first: the level's first iteration (P = 4 with deferred H: it also accumulates the H partials)
+// ev0 / ev1 (optional, timing runs): HIP events that take the kernel's own start and end time stamps (hipExtLaunchKernelGGL:
+// the dispatch's completion-signal times, what rocprofv3's kernel trace lists), not the time between two event packets
 void launch_iter_main(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
-                      int first, hipStream_t s) {
+                      int first, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const dim3 blk(kBlock);
-  if (e.P == 8 && !(variant & 2)) {
+#define ICTR_LAUNCH(kern, grid, ...)                                                      \
+  do {                                                                                    \
+    if (ev0 && ev1)                                                                       \
+      hipExtLaunchKernelGGL(kern, grid, blk, 0, s, ev0, ev1, 0, __VA_ARGS__);             \
+    else                                                                                  \
+      hipLaunchKernelGGL(kern, grid, blk, 0, s, __VA_ARGS__);                             \
+  } while (0)
+  if (fast8(e, variant)) {
     const dim3 g8(gridx8, e.B);
-    // patches per pipeline step: 4 measured best (profiles/r01_notes.md); variant bits 4-5 select others for A/B
-    const int ku = (variant >> 4) & 3;
-    // stage-2 addressing (see k_iter8): buffer loads + per-lane taps (LD = 2) measured best (r02: levels 1 / 2 195 ->
-    // 183 / 182 -> 165 us per launch), LD = 3 trims its per-patch bookkeeping; variant bits 16-17 = 1 / 2 / 3 select
-    // LD = 0 / 1 / 2 for A/B
-    const int ldsel = (variant >> 16) & 3;
-    if (first && defer_h(e, variant)) {
-      if (e.dopatchnorm && ldsel == 3)
-        hipLaunchKernelGGL((k_iter8<true, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
-      else if (e.dopatchnorm)
-        hipLaunchKernelGGL((k_iter8<true, 2, true, true, 3>), g8, blk, 0, s, e, lc, level, cpw);
-      else if (ldsel == 1)
-        hipLaunchKernelGGL((k_iter8<false, 4, true, true, 0>), g8, blk, 0, s, e, lc, level, cpw);
-      else if (variant & (1 << 20))  // A/B: four patches per step like the regular launches (116 VGPRs, occupancy 4)
-        hipLaunchKernelGGL((k_iter8<false, 4, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
-      else if (ldsel == 3)
-        hipLaunchKernelGGL((k_iter8<false, 2, true, true, 2>), g8, blk, 0, s, e, lc, level, cpw);
-      else  // the H-accumulating launch carries 21 more accumulators: two patches per step keep it at ~81 VGPRs /
-            // occupancy 5 (r02: 258 -> 195 us wall per 16-pair launch beside the other engine, step 6.34 -> 6.30 ms)
-        hipLaunchKernelGGL((k_iter8<false, 2, true, true, 3>), g8, blk, 0, s, e, lc, level, cpw);
-    } else if (e.dopatchnorm && ldsel == 3)
-      hipLaunchKernelGGL((k_iter8<true, 2, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_iter8<true, 2, true, false, 3>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (ku == 1)
-      hipLaunchKernelGGL((k_iter8<false, 1, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (ku == 2)
-      hipLaunchKernelGGL((k_iter8<false, 2, true, false, 3>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (ku == 3)
-      hipLaunchKernelGGL((k_iter8<false, 4, false, false, 2>), g8, blk, 0, s, e, lc, level, cpw);  // A/B: temporal loads
-    else if (ldsel == 1)
-      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 0>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (ldsel == 2)
-      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 1>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (ldsel == 3)
-      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 2>), g8, blk, 0, s, e, lc, level, cpw);
+    // patches per pipeline step: 4 measured best (profiles/r01_notes.md); variant bits 4-5 = 2: two (A/B)
+    if (e.dopatchnorm)
+      ICTR_LAUNCH((k_iter8<true, 2>), g8, e, lc, level, cpw);
+    else if (((variant >> 4) & 3) == 2)
+      ICTR_LAUNCH((k_iter8<false, 2>), g8, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL((k_iter8<false, 4, true, false, 3>), g8, blk, 0, s, e, lc, level, cpw);
+      ICTR_LAUNCH((k_iter8<false, 4>), g8, e, lc, level, cpw);
   } else if (fast4(e, variant)) {
     const dim3 g8(gridx8, e.B);
     if (first) {
       if (e.dopatchnorm)
-        hipLaunchKernelGGL((k_iter4<true, true>), g8, blk, 0, s, e, lc, level, cpw);
+        ICTR_LAUNCH((k_iter4<true, true>), g8, e, lc, level, cpw);
       else
-        hipLaunchKernelGGL((k_iter4<false, true>), g8, blk, 0, s, e, lc, level, cpw);
+        ICTR_LAUNCH((k_iter4<false, true>), g8, e, lc, level, cpw);
     } else if (e.dopatchnorm)
-      hipLaunchKernelGGL((k_iter4<true, false>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (((variant >> 4) & 3) == 3)
-      hipLaunchKernelGGL((k_iter4<false, false, 4>), g8, blk, 0, s, e, lc, level, cpw);
-    else if (((variant >> 4) & 3) == 1)
-      hipLaunchKernelGGL((k_iter4<false, false, 1>), g8, blk, 0, s, e, lc, level, cpw);
+      ICTR_LAUNCH((k_iter4<true, false>), g8, e, lc, level, cpw);
     else
-      hipLaunchKernelGGL((k_iter4<false, false>), g8, blk, 0, s, e, lc, level, cpw);
+      ICTR_LAUNCH((k_iter4<false, false>), g8, e, lc, level, cpw);
   } else if (e.P == 4)
-    hipLaunchKernelGGL((k_iter<4>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
+    ICTR_LAUNCH((k_iter<4>), dim3(gridx, e.B), e, lc, level);
   else
-    hipLaunchKernelGGL((k_iter<0>), dim3(gridx, e.B), blk, 0, s, e, lc, level);
+    ICTR_LAUNCH((k_iter<0>), dim3(gridx, e.B), e, lc, level);
+#undef ICTR_LAUNCH
 }
 // ... and steps 9b-10 (one workgroup per problem)
 void launch_iter_tail(const EngineDev &e, int level, int gridx, int variant, int gridx8, int first, hipStream_t s) {
@@ -1763,7 +1590,7 @@ void launch_iter_tail(const EngineDev &e, int level, int gridx, int variant, int
 }
 void launch_iter(const EngineDev &e, const LevelCam &lc, int level, int gridx, int variant, int cpw, int gridx8,
                  int first, hipStream_t s) {
-  launch_iter_main(e, lc, level, gridx, variant, cpw, gridx8, first, s);
+  launch_iter_main(e, lc, level, gridx, variant, cpw, gridx8, first, s, nullptr, nullptr);
   launch_iter_tail(e, level, gridx, variant, gridx8, first, s);
 }
 void launch_iter_finish(const EngineDev &e, int level, int variant, int first, hipStream_t s) {

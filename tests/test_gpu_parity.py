@@ -311,7 +311,9 @@ def test_team_form_batches_ragged_shares_and_repeated_launches(oracle):
     assert "k_iter" in name
     # poses to float noise where the system is well determined; a 17-point problem carries more of the summation
     # order, a 1-point problem is rank deficient (its update is whatever the rank decision leaves): finite and close
-    tol = np.array([5e-6 if c >= 90 else (1e-4 if c >= 10 else 1e-2) for c in counts])[:, None]
+    # (r03: the per-iteration launches take H from three sums per patch, the one-launch tracker from 21 sums per pixel:
+    # the same H to ~1e-7, so poses of ~0.5 agree to a few 1e-6 after 18 iterations instead of a few 1e-7)
+    tol = np.array([2e-5 if c >= 90 else (1e-4 if c >= 10 else 1e-2) for c in counts])[:, None]
 
     def close(a, b):
         return bool(np.all(np.isfinite(a)) and np.all(np.abs(a - b) <= tol))
@@ -324,7 +326,7 @@ def test_team_form_batches_ragged_shares_and_repeated_launches(oracle):
         assert np.array_equal(got[0][1][strong], ref[0][1][strong])
     refs, _, _ = run(LAUNCHES, None, swap=True)
     gots, _, nteam = run(0, (32, 0, 1 << 30), swap=True)
-    assert nteam == 22 and close(gots[0][0], refs[0][0])
+    assert nteam == 22 and close(gots[0][0], refs[0][0]), np.abs(gots[0][0] - refs[0][0]).max(axis=1)
 
 
 def test_team_launches_on_many_streams_are_admitted_without_starving_each_other(oracle):
@@ -397,7 +399,7 @@ def test_resident_iterations_equal_per_iteration_launches(oracle, B, ratio, maxi
     for r, l in zip(out["resident"][0], out["launches"][0]):
         # 640 px frames: the tap-selection quirk of the module docstring; with an exit threshold a level may also end one
         # iteration earlier in one form (the last steps are ~1e-4)
-        assert np.abs(r[0] - l[0]).max() <= (2e-5 if ratio == 0.0 else 2e-4)
+        assert np.abs(r[0] - l[0]).max() <= (5e-5 if ratio == 0.0 else 2e-4), np.abs(r[0] - l[0]).max(axis=1)
         if ratio == 0.0:
             assert np.array_equal(r[1], l[1])
         assert all(np.array_equal(x, y) for x, y in zip(r[2], l[2])), "patch buffers differ between the launch forms"

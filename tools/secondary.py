@@ -15,6 +15,7 @@ Imported by bench.py only after the headline measurement is complete.
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -154,7 +155,7 @@ def _small_scene(w, h, n, seed=5):
     return synth.make_scene(w, h, n_points=n, seed=seed)
 
 
-def rec_nposes(seconds):
+def rec_nposes(seconds, cpu_track=None):
     """500 pose samples x 60 points, 5 frame pairs forward + 5 backward (run_ransac_test.m:67,88,
     func_ransac_fitcameras_odom.m: psz 8, 5 levels, maxiter 10, normdp_ratio 0.01): every chain link is ONE batch
     tracking of all samples (samples are independent problems, run_track_nposes.cpp:193)."""
@@ -185,17 +186,35 @@ def rec_nposes(seconds):
     p = chain()
     its = eng.iterations()
     pix = float(its.sum()) * n * P * P * links  # executed iterations of the last link x links (same inputs each link)
-    return {"name": "nposes", "workload": f"run_track_nposes shape: {S} pose samples x {n} points x {links} frame "
+    cpu = {}
+    if cpu_track is not None:
+        # the CPU path on the FIRST chain link of a few samples (same start poses, frames, points, options): ms per
+        # tracking on one host core, and the GPU batch's poses of that link against it
+        eng.SetPoseAll(starts, pa, pb)
+        eng.track_async()
+        p1 = eng.poses()
+        ks = list(range(0, S, S // 8))[:8]
+        ms, diff = [], 0.0
+        for k in ks:
+            pc, m, _ = cpu_track(sc, lv_f, P, 10, 0.01, n, seconds=0.0, p_start=starts[k])
+            ms.append(m)
+            diff = max(diff, float(np.abs(p1[k] - pc).max()))
+        cores = os.cpu_count() or 1
+        cpu = {"cpu_ms_per_tracking": float(np.mean(ms)), "cpu_samples": len(ks), "pose_diff_vs_cpu": diff,
+               "cpu_trackings_per_s_one_core": 1e3 / float(np.mean(ms)),
+               "cpu_trackings_per_s_all_host_cores_extrapolated": cores * 1e3 / float(np.mean(ms)), "host_cores": cores}
+    return {**cpu, "name": "nposes", "workload": f"run_track_nposes shape: {S} pose samples x {n} points x {links} frame "
             f"pairs (chained), 8x8 patches, 5 levels, maxiter 10, normdp_ratio 0.01, {w}x{h}",
             "value": S * links / dt, "unit": "trackings/s", "ms_per_step": dt * 1e3, "ms_per_chain_link": dt * 1e3 / links,
             "reps": reps, "kernel": eng.path_name() if hasattr(eng, "path_name") else "k_iter8 (per-iteration launches)",
             "mean_iterations": float(its.mean()), "aligned_Mpix_per_s": pix / dt / 1e6,
             "algorithmic_bytes_per_launch": None, "frac": None,
-            "note": "latency-bound (60-point problems): reported as trackings/s, not against the HBM roofline",
+            "note": "latency-bound (60-point problems): reported as trackings/s, not against the HBM roofline; pose_diff_vs_cpu "
+                    "= first chain link of 8 samples against the oracle (early exit on: iteration counts may differ)",
             "pose_err_vs_ground_truth_median": float(np.median(np.abs(p - sc["p_a"][None, :]).max(1)))}
 
 
-def rec_dense(seconds):
+def rec_dense(seconds, cpu_track=None):
     """The headline's frame pair as the reference would run it: ONE dense 1080p pair (and a batch of 4) per tracking,
     SetPose + TrackPose + poses on the host. Default = k_level_resident (all iterations of a level in one launch,
     templates resident on the chip); the streaming per-iteration kernels beside it (variant bit 21)."""
@@ -208,6 +227,7 @@ def rec_dense(seconds):
     cam = ic.CamClass(lv_f + 1, sc["fc"], sc["cc"], sc["wh"], P)
     pa, pb = ic.Pyramid(sc["img_a"], lv_f, P), ic.Pyramid(sc["img_b"], lv_f, P)
     cases = []
+    poses_1 = {}
     for B in (1, 4):
         row = {"pairs": B, "points_per_pair": n}
         for name, variant in (("default", 0), ("streaming", 1 << 21)):
@@ -232,9 +252,16 @@ def rec_dense(seconds):
             row[name + "_ms"] = float(np.median(ts)) * 1e3
             row[name + "_kernel"] = eng.path_name()
             row[name + "_pose_err_vs_ground_truth"] = float(np.abs(p - sc["p_b"][None, :]).max())
+            if B == 1:
+                poses_1[name] = p[0].copy()
         cases.append(row)
     pix = 30.0 * n * P * P
-    return {"name": "dense", "workload": f"ONE dense {w}x{h} frame pair per tracking ({n} 8x8 patches, 3 levels x 10 "
+    cpu = {}
+    if cpu_track is not None:
+        pc, m, runs = cpu_track(sc, lv_f, P, 10, 0.0, n, seconds=0.0)
+        cpu = {"cpu_ms": m, "cpu_runs": runs,
+               "pose_diff_vs_cpu": {k_: float(np.abs(v_ - pc).max()) for k_, v_ in poses_1.items()}}
+    return {**cpu, "name": "dense", "workload": f"ONE dense {w}x{h} frame pair per tracking ({n} 8x8 patches, 3 levels x 10 "
             "iterations), host calls included; and a batch of 4", "value": cases[0]["default_ms"], "unit": "ms per tracking "
             "(1 pair)", "aligned_Mpix_per_s": pix / (cases[0]["default_ms"] * 1e-3) / 1e6, "cases": cases,
             "kernel": cases[0]["default_kernel"], "algorithmic_bytes_per_launch": None, "frac": None,
@@ -242,7 +269,7 @@ def rec_dense(seconds):
                     "broadcast), not a stream of T/Gx/Gy from HBM"}
 
 
-def rec_small(seconds):
+def rec_small(seconds, cpu_track=None):
     import invcompcamtrack_amd as ic
     out = []
     cases = ((640, 480, 100, 1), (640, 480, 300, 1), (640, 480, 1000, 1), (640, 480, 5000, 1), (640, 480, 300, 64))
@@ -273,7 +300,11 @@ def rec_small(seconds):
             t0 = time.perf_counter()
             p = step()
             ts.append(time.perf_counter() - t0)
-        out.append({"points": n, "problems": B, "frame": f"{w}x{h}", "levels": lv_f + 1, "maxiter": 10,
+        cpu = {}
+        if cpu_track is not None:
+            pc, m, runs = cpu_track(sc, lv_f, P, 10, 0.0, n, seconds=0.15)
+            cpu = {"cpu_ms": m * B, "cpu_runs": runs, "pose_diff_vs_cpu": float(np.abs(p - pc[None, :]).max())}
+        out.append({**cpu, "points": n, "problems": B, "frame": f"{w}x{h}", "levels": lv_f + 1, "maxiter": 10,
                     "ms": float(np.median(ts)) * 1e3,
                     "kernel": eng.path_name() if hasattr(eng, "path_name") else "per-iteration launches",
                     "pose_err_vs_ground_truth": float(np.abs(p - sc["p_b"][None, :]).max())})
@@ -316,12 +347,14 @@ def rec_pyramid(seconds):
             "note": "three dependent launches per frame; bit-exact against the oracle (tests/test_gpu_pyramid_patch.py)"}
 
 
-def run_all(seconds=1.0):
+def run_all(seconds=1.0, cpu_track=None):
+    """cpu_track: bench.py's cpu_baseline leg (the oracle on one tracking -> pose, ms, runs); tools/ never imports the
+    oracle itself. None: no CPU figures."""
     recs = []
     for fn in (rec_psz4, rec_c3, rec_c5, rec_c4, rec_nposes, rec_small, rec_dense, rec_pyramid):
         t0 = time.perf_counter()
         try:
-            r = fn(seconds)
+            r = fn(seconds, cpu_track) if fn in (rec_nposes, rec_small, rec_dense) else fn(seconds)
         except Exception as exc:  # a secondary record must never take the headline down
             r = {"name": fn.__name__[4:], "error": repr(exc)}
         r["wall_s"] = round(time.perf_counter() - t0, 2)
