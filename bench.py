@@ -63,11 +63,11 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel-selection bits for A/B runs (include/ictr.h, ictr_odometer_set_variant)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="skip the in-stream HIP-event kernel timing")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="single-GPU mode: split the B pairs over this many engines on their own HIP streams and run "
-                         "them concurrently (default 2: one engine's latency-bound setup kernel, tails and launch gaps "
-                         "overlap the other's HBM-bound iteration kernel; the roofline then uses fair-share launch "
-                         "durations, see roofline.duration_basis). 1 = strictly serial kernels")
+                         "them concurrently. 0 (default) = 1 with the resident-iteration form (its launches fill the "
+                         "chip one at a time), 2 with the streaming kernels (variant bit 21: one engine's latency-bound "
+                         "setup kernel, tails and launch gaps overlap the other's HBM-bound iteration kernel)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one engine, host and GPU strictly alternate (the pre-pipelining behaviour)")
     ap.add_argument("--groups", type=int, default=0,
@@ -175,9 +175,10 @@ def build_inputs(args, rank, world):
             pts = pts + rng.normal(0, 1e-3, pts.shape) * np.array([[1.0], [1.0], [0.0]])
         points.append(np.ascontiguousarray(pts))
 
-    def make_engines(n_parts, split):
+    def make_engines(n_parts, split, variant=None):
         """split=False: n_parts engines that each hold all B pairs (they take the steps in turn);
         split=True: the B pairs divided into n_parts groups (sharded mode)."""
+        variant = args.variant if variant is None else variant
         per = args.batch // n_parts if split else args.batch
         engs = [ic.TrackBatch(cam, op, per) for _ in range(n_parts)]
         for b in range(args.batch):
@@ -187,7 +188,7 @@ def build_inputs(args, rank, world):
                 for e in engs:
                     e.Set3Dpoints(b, points[b].copy())
         for e in engs:
-            e.set_variant(args.variant)
+            e.set_variant(variant)
             if not args.no_events:
                 e.set_timing(True)
         return engs
@@ -405,7 +406,7 @@ def main():
     if sharded:
         from invcompcamtrack_amd.dist import ShardedTracker
     else:
-        n_streams = max(1, args.streams)
+        n_streams = args.streams if args.streams > 0 else (2 if (args.variant & (1 << 21)) else 1)
         if B % n_streams:
             raise SystemExit("--streams must divide --batch")
         depth = 1 if args.no_pipeline else 2
@@ -609,157 +610,185 @@ def main():
             "pose_err_vs_ground_truth": err,
         }
         if not args.no_events:
-            # the dominant kernel = the GN-iteration accumulate kernel (k_iter8): every launch, at every level, processes
-            # the same pairs x N x 64 pixels, so its mean duration over ALL launches is what rocprofv3 --stats reports too
             eng_list = tracker.batches if sharded else holders[0].engs
             pairs_per_launch = eng_list[0].B           # pairs per engine: B / streams (B / groups in the sharded mode)
             n_eng_step = len(eng_list)
             overlapping = n_eng_step > 1               # launches of different engines share the GPU
-            # (Since r03 a level's first iteration launch is the same instantiation as the others -- H comes from the
-            # setup kernel's three sums per patch -- but it is still reported separately: it starts on cold caches.)
-            n_reg = args.steps * n_eng_step * (args.maxiter - 1) * args.levels
-            n_first = args.steps * n_eng_step * args.levels
             nl = args.steps * n_eng_step * args.maxiter
-            n_all = n_reg + n_first
-            # small batches (<= 8 pairs per engine) run a level's iterations as ONE k_level_resident launch: there is no
-            # per-iteration launch to time; an "iteration" is then the level's launch / maxiter (per_level events)
+            n_all = nl * args.levels
+            n_first = args.steps * n_eng_step * args.levels
+            # resident-iteration form: a level's iterations are ONE k_level_resident launch (no per-iteration events)
             resident_form = float(ev_kernel.sum()) == 0.0 and float(ev_iters.sum()) > 0.0
-            if resident_form:
-                ev_kernel = ev_iters.copy()
-                ev_first = ev_iters / args.maxiter
-                intervals.clear()
-            t_all = float(ev_kernel.sum()) / max(n_all, 1) * 1e-3          # s per launch, EVERY k_iter8 launch
-            t_kernel = float(ev_kernel.sum() - ev_first.sum()) / max(n_reg, 1) * 1e-3  # regular instantiation alone
-            t_first = float(ev_first.sum()) / max(n_first, 1) * 1e-3
-            if n_reg == 0:
-                t_kernel = t_first
-            alg = 16.0 * pix_per_iter * pairs_per_launch
+            alg_iter = 16.0 * pix_per_iter * pairs_per_launch   # one GN iteration of the engine's pairs
             # unique bytes: T, Gx, Gy are 12 B per patch pixel at every level; the current-frame texel is unique only
             # at level 0 (8-px grid = patch size). At level l the centres are 8/2^l px apart, so the 8x8 patches
             # overlap 4^l-fold and a launch touches 4 / 4^l B of distinct frame bytes per patch pixel.
-            lv_l = 0
-            uniq_bpp = [12.0 + 4.0 / (4.0 ** l) for l in range(lv_l, lv_l + args.levels)]
-            traffic, traffic_source = None, None
-            for tname in ("traffic_r02.json", "traffic_r01.json"):
-                tpath = os.path.join(ROOT, "profiles", tname)
-                if not os.path.exists(tpath):
-                    continue
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts:
-                        traffic = tj.get("hbm_bytes_per_launch_mean")
-                        traffic_source = (f"profiles/{tname}: rocprofv3 --pmc passes of this command collected in "
-                                          "their own runs (FETCH_SIZE x 2 + WRITE_SIZE); static, NOT measured in this run")
-                        break
-                except Exception:
-                    traffic = None
-            per_level_all = [float(x) / nl * 1e3 for x in ev_kernel]
-            # Concurrent engines: launches of different streams overlap, so a launch's wall-clock duration is not the
-            # machine time its bytes needed. Fair share: at any moment the GPU is split evenly between the big kernels in
-            # flight (k_iter8 launches and the other stream's setup launch; the tails are 3 us each and ignored), so a
-            # launch is charged the integral of 1 / (number of kernels in flight) over its interval, and
-            #   achieved = all algorithmic bytes of the timed k_iter8 launches / machine time charged to k_iter8.
-            # With one stream nothing overlaps and this is exactly bytes per launch / mean launch duration.
-            charged = 0.0
-            if intervals:
-                evs = []
-                for x, y in intervals:
-                    evs += [(x, 1, 0), (y, -1, 0)]
-                for x, y in other_intervals:
-                    evs += [(x, 0, 1), (y, 0, -1)]
-                evs.sort()
-                n_it = n_ot = 0
-                t_prev = evs[0][0]
-                for t, di, do in evs:
-                    if n_it > 0:
-                        charged += (t - t_prev) * n_it / (n_it + n_ot)
-                    t_prev = t
-                    n_it += di
-                    n_ot += do
-            n_iv = max(len(intervals), 1)
-            t_fair = charged * 1e-3 / n_iv if (overlapping and intervals) else t_all   # s per launch, fair share
-            busy = charged
-            # roofline.frac = the UN-OVERLAPPED figure: bytes of a launch / the duration of that launch running alone
-            # (one stream: the timed launches themselves; two streams: the same engines and launches once more on ONE
-            # stream right after the timed region, `solo` below). The fair-share figure of the overlapped timed region
-            # is kept as roofline.fair_share (it charges k_iter8 half of every interval it shares with the other
-            # stream's setup kernel whoever used the HBM, and cannot be recomputed from a --stats summary).
-            solo = None
-            if overlapping and not sharded and streams[0] is not None and not resident_form:
-                h0 = holders[0]
-                for e_ in h0.engs:
-                    e_.set_stream(streams[0].cuda_stream)
-                solo_sum, solo_first, solo_steps = 0.0, 0.0, 4
-                solo_lv = np.zeros(args.levels)
-                # marker in the kernel trace: the solo leg = the k_iter8 dispatches behind the LAST k_stream_read
-                # dispatch (profiles/recompute_roofline.py); also the streaming-read yardstick once more, warm
-                stream_gbps2 = ctypes.c_double(0.0)
-                _lib.check(_lib.load().ictr_stream_read_bandwidth(1 << 30, 2, ctypes.byref(stream_gbps2)))
-                for _ in range(solo_steps):
-                    h0.setpose_all()
-                    h0.track()
-                    h0.poses()
-                    for e_ in h0.engs:
+            uniq_bpp = [12.0 + 4.0 / (4.0 ** l) for l in range(args.levels)]
+
+            def load_traffic(kernel_key):
+                for tname in ("traffic_r03.json", "traffic_r02.json"):
+                    tpath = os.path.join(ROOT, "profiles", tname)
+                    if not os.path.exists(tpath):
+                        continue
+                    try:
+                        tj = json.load(open(tpath))
+                        if tj.get("kernel", "k_iter8") == kernel_key and tj.get("batch") == pairs_per_launch and tj.get("points") == n_pts:
+                            return tj.get("hbm_bytes_per_launch_mean"), (
+                                f"profiles/{tname}: rocprofv3 --pmc passes of this command collected in their own runs "
+                                "(FETCH_SIZE x 2 + WRITE_SIZE); static, NOT measured in this run")
+                    except Exception:
+                        pass
+                return None, None
+
+            def streaming_leg(engs, stream_ptr, steps):
+                """k_iter8 on its own: `engs` (per-iteration launches) run on ONE stream behind a k_stream_read marker;
+                mean HIP-event duration (the dispatch's own start / end stamps) of every k_iter8 launch."""
+                gb = ctypes.c_double(0.0)
+                _lib.check(_lib.load().ictr_stream_read_bandwidth(1 << 30, 2, ctypes.byref(gb)))
+                per = engs[0].B
+                tot, first, lv = 0.0, 0.0, np.zeros(args.levels)
+                for st_ in range(steps + 1):
+                    for k_, e_ in enumerate(engs):
+                        e_.set_stream(stream_ptr)
+                        for b_ in range(per):
+                            pa_, pb_ = pyrs[k_ * per + b_]
+                            e_.SetPose(b_, scenes[(k_ * per + b_) % 2]["p_a"], pa_, pb_)
+                    for e_ in engs:
+                        e_.track_async()
+                    for e_ in engs:
+                        e_.poses()
+                        if st_ == 0:
+                            continue  # warm-up
                         kt_ = e_.kernel_times()
-                        solo_lv += kt_
-                        solo_sum += float(kt_.sum())
-                        solo_first += float(e_.first_iter_times().sum())
-                for e_, st in zip(h0.engs, streams):
-                    e_.set_stream(st.cuda_stream)
-                n_solo = solo_steps * n_eng_step * args.maxiter * args.levels
-                solo = {"t": solo_sum / max(n_solo, 1) * 1e-3, "n": n_solo, "stream_after": stream_gbps2.value,
-                        "regular_us": (solo_sum - solo_first) / max(solo_steps * n_eng_step * (args.maxiter - 1) * args.levels, 1) * 1e3,
-                        "first_us": solo_first / max(solo_steps * n_eng_step * args.levels, 1) * 1e3,
-                        "per_level_us": [float(x) / (solo_steps * n_eng_step * args.maxiter) * 1e3 for x in solo_lv]}
-            t_roof = solo["t"] if solo else t_all
-            if solo:
-                basis = ("un-overlapped: the same engines and launches (same kernels, grids and bytes as the timed steps) "
-                         f"run on ONE stream right after the timed region, mean HIP-event duration of all {solo['n']} "
-                         "k_iter8 launches; reproducible from the rocprofv3 kernel trace of this command "
-                         "(profiles/recompute_roofline.py: mean duration of the k_iter8 dispatches behind the last "
-                         "k_stream_read marker)")
-            elif resident_form:
-                basis = "level launch / maxiter (HIP events around each k_level_resident launch)"
+                        lv += kt_
+                        tot += float(kt_.sum())
+                        first += float(e_.first_iter_times().sum())
+                n = steps * len(engs) * args.maxiter * args.levels
+                t = tot / max(n, 1) * 1e-3
+                a_ = 16.0 * pix_per_iter * per
+                return {"kernel": "k_iter8 (GN iteration: steps 7-9a), every launch of every level, running alone",
+                        "pairs_per_launch": per, "algorithmic_bytes_per_launch": a_, "us_per_launch": t * 1e6,
+                        "launches_timed": n, "achieved": a_ / t / 1e9, "frac": a_ / t / 1e9 / 8000.0,
+                        "regular_launch_us": (tot - first) / max(steps * len(engs) * (args.maxiter - 1) * args.levels, 1) * 1e3,
+                        "first_iteration_launch_us": first / max(steps * len(engs) * args.levels, 1) * 1e3,
+                        "per_level_kernel_us": [float(x) / (steps * len(engs) * args.maxiter) * 1e3 for x in lv],
+                        "measured_stream_read_GBps_before_leg": gb.value,
+                        "basis": "same engines / kernels / grids as a tracking step, on ONE stream behind a k_stream_read "
+                                 "marker (nothing overlaps): mean HIP-event duration (hipExtLaunchKernel start / stop stamps = "
+                                 "the dispatch's own begin and end) of every k_iter8 launch; profiles/recompute_roofline.py "
+                                 "derives the same figure from the rocprofv3 kernel trace of the same command"}
+
+            fair = None
+            if resident_form:
+                # ---- headline kernel: k_level_resident, one launch per level and engine
+                n_launch = args.steps * n_eng_step * args.levels
+                t_launch = float(ev_iters.sum()) / max(n_launch, 1) * 1e-3
+                alg = alg_iter * args.maxiter
+                traffic, traffic_source = load_traffic("k_level_resident")
+                roof = {"kernel": "k_level_resident: ALL Gauss-Newton iterations of a pyramid level in one launch, templates "
+                                  "resident in registers / LDS (one launch per level; steps 7-10 of odometer.cpp:344-418)",
+                        "algorithmic_bytes_per_launch": alg, "us_per_launch": t_launch * 1e6, "launches_timed": n_launch,
+                        "achieved": alg / t_launch / 1e9, "frac": alg / t_launch / 1e9 / 8000.0,
+                        "duration_basis": "HIP events on the engine's stream around each k_level_resident launch of the timed "
+                                          "steps (nothing overlaps: one engine, one stream)",
+                        "note": "algorithmic bytes = SURVEY.md 8d's 16 B per patch pixel and iteration x maxiter x the launch's "
+                                "pixels. This kernel does NOT move them: T / Gx / Gy are loaded once per level and stay on "
+                                "the chip, an iteration reads only the cache-resident current frame -- `traffic` is what "
+                                "crosses HBM. `achieved` is therefore an equivalent rate and can exceed the HBM peak; the "
+                                "kernel is bound by its per-iteration latency chain (two mailbox hops + solve), not by "
+                                "bandwidth. The streaming kernel's own figure is roofline.streaming_kernel.",
+                        "per_level_launch_us": [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_iters],
+                        "us_per_iteration_equivalent": t_launch * 1e6 / args.maxiter}
+                # the streaming form beside it (the kernel every other configuration runs: sharded multi-GPU mode, small
+                # patch sizes, robustness options): one 16-pair engine with variant bit 21, its launches alone
+                try:
+                    sub = inp["make_engines"](2 if B % 2 == 0 else 1, split=True, variant=args.variant | (1 << 21))[:1]
+                    leg = streaming_leg(sub, 0, 2)
+                    leg["traffic"], leg["traffic_source"] = None, None
+                    for tname in ("traffic_r02.json",):
+                        tpath = os.path.join(ROOT, "profiles", tname)
+                        if os.path.exists(tpath):
+                            tj = json.load(open(tpath))
+                            if tj.get("batch") == sub[0].B and tj.get("points") == n_pts:
+                                leg["traffic"] = tj.get("hbm_bytes_per_launch_mean")
+                                leg["traffic_source"] = f"profiles/{tname} (PMC passes, static)"
+                    roof["streaming_kernel"] = leg
+                    del sub
+                except Exception as exc:  # never take the headline down
+                    roof["streaming_kernel"] = {"error": repr(exc)}
             else:
-                basis = "mean launch duration (HIP events around each launch; nothing overlaps)"
+                # ---- headline kernel: k_iter8 (per-iteration launches)
+                t_all = float(ev_kernel.sum()) / max(n_all, 1) * 1e-3          # s per launch, EVERY k_iter8 launch (wall)
+                traffic, traffic_source = load_traffic("k_iter8")
+                if overlapping and not sharded and streams[0] is not None:
+                    # Two engines on two streams: a launch's wall-clock duration includes the time it shared the GPU.
+                    # roofline.frac = the UN-OVERLAPPED figure (the same engines once more on ONE stream right after the
+                    # timed region); the fair-share figure of the overlapped region stays as roofline.fair_share: every
+                    # launch is charged the integral of 1 / (big kernels in flight) over its interval.
+                    charged = 0.0
+                    if intervals:
+                        evs = []
+                        for x, y in intervals:
+                            evs += [(x, 1, 0), (y, -1, 0)]
+                        for x, y in other_intervals:
+                            evs += [(x, 0, 1), (y, 0, -1)]
+                        evs.sort()
+                        n_it = n_ot = 0
+                        t_prev = evs[0][0]
+                        for t, di, do in evs:
+                            if n_it > 0:
+                                charged += (t - t_prev) * n_it / (n_it + n_ot)
+                            t_prev = t
+                            n_it += di
+                            n_ot += do
+                        t_fair = charged * 1e-3 / max(len(intervals), 1)
+                        fair = {"achieved": alg_iter / t_fair / 1e9, "frac": alg_iter / t_fair / 1e9 / 8000.0,
+                                "us_per_launch": t_fair * 1e6, "wall_us_per_launch": t_all * 1e6,
+                                "overlap_factor": float(ev_kernel.sum()) / charged if charged > 0 else 1.0,
+                                "launches_timed": n_all,
+                                "basis": "timed region, two engines on two streams: every launch is charged the integral of "
+                                         "1 / (kernels in flight) over its interval (HIP events of all k_iter8 and setup "
+                                         "launches on a common time base); wall_us_per_launch is what rocprofv3 --stats "
+                                         "averages over the overlapped launches"}
+                    roof = streaming_leg(holders[0].engs, streams[0].cuda_stream, 4)
+                    for e_, st in zip(holders[0].engs, streams):
+                        e_.set_stream(st.cuda_stream)
+                    roof["duration_basis"] = roof.pop("basis")
+                else:
+                    t_first = float(ev_first.sum()) / max(n_first, 1) * 1e-3
+                    roof = {"kernel": "k_iter8 (GN iteration: steps 7-9a), every launch of every level",
+                            "algorithmic_bytes_per_launch": alg_iter, "us_per_launch": t_all * 1e6, "launches_timed": n_all,
+                            "achieved": alg_iter / t_all / 1e9, "frac": alg_iter / t_all / 1e9 / 8000.0,
+                            "duration_basis": "mean launch duration (HIP events around each launch; nothing overlaps)",
+                            "regular_launch_us": float(ev_kernel.sum() - ev_first.sum()) / max(n_all - n_first, 1) * 1e3,
+                            "first_iteration_launch_us": t_first * 1e6,
+                            "per_level_kernel_us": [float(x) / nl * 1e3 for x in ev_kernel]}
             # end to end: ALL algorithmic bytes of a step (16 B per patch pixel and iteration + the level setup's 12 B read
             # + 12 B written per patch pixel, SURVEY.md 8d) over the step's wall time -- gaps, tails and host included
             e2e_bytes = float(B) * args.levels * pix_per_iter * (16.0 * args.maxiter + 24.0)
             e2e_rate = e2e_bytes / (dt / args.steps) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": alg / t_roof / 1e9, "peak": 8000.0, "unit": "GB/s",
-                               "frac": alg / t_roof / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                               "kernel": ("k_level_resident (all iterations of a level in one launch, templates resident "
-                                          "on the chip): per iteration = launch / maxiter; its bytes do not cross HBM, so "
-                                          "`achieved` is an equivalent rate, not HBM traffic" if resident_form else
-                                          "k_iter8 (GN iteration: steps 7-9a), every launch of every level"),
-                               "algorithmic_bytes_per_launch": alg, "us_per_launch": t_roof * 1e6,
-                               "launches_timed": solo["n"] if solo else n_all,
-                               "duration_basis": basis,
+            setup_us = [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_setup] if not sharded else None
+            out["roofline"] = {"bound": "hbm", "achieved": roof.pop("achieved"), "peak": 8000.0, "unit": "GB/s",
+                               "frac": roof.pop("frac"), "traffic": traffic, "traffic_source": traffic_source, **roof,
                                "end_to_end": {"algorithmic_bytes_per_step": e2e_bytes, "achieved": e2e_rate,
                                               "frac": e2e_rate / 8000.0,
                                               "basis": "frame pairs x levels x patch pixels x (16 B x maxiter + 24 B setup) "
                                                        "/ ms_per_step / 8 TB/s (per GPU)"},
-                               "fair_share": ({"achieved": alg / t_fair / 1e9, "frac": alg / t_fair / 1e9 / 8000.0,
-                                               "us_per_launch": t_fair * 1e6, "wall_us_per_launch": t_all * 1e6,
-                                               "overlap_factor": float(ev_kernel.sum()) / busy if busy > 0 else 1.0,
-                                               "launches_timed": n_all,
-                                               "basis": "timed region, two engines on two streams: every launch is charged "
-                                                        "the integral of 1 / (kernels in flight) over its interval (HIP "
-                                                        "events of all k_iter8 and setup launches on a common time base); "
-                                                        "wall_us_per_launch is what rocprofv3 --stats averages over the "
-                                                        "overlapped launches"}
-                                              if (overlapping and intervals) else None),
-                               "regular_launch_us": solo["regular_us"] if solo else t_kernel * 1e6,
-                               "first_iteration_launch_us": solo["first_us"] if solo else t_first * 1e6,
+                               "fair_share": fair,
                                "measured_stream_read_GBps": stream_gbps.value,
-                               "measured_stream_read_GBps_after_timed_region": solo["stream_after"] if solo else None,
-                               "frac_of_measured_stream_read": alg / t_roof / 1e9 / max(stream_gbps.value, 1e-9),
-                               "per_level_kernel_us": solo["per_level_us"] if solo else per_level_all,
                                "per_level_bytes_unique_per_px": uniq_bpp,
                                "per_level_us_per_iteration_incl_tail_and_gaps":
                                    [float(x) / nl * 1e3 for x in ev_iters] if not sharded else None,
-                               "per_level_setup_us":
-                                   [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_setup] if not sharded else None}
+                               "per_level_setup_us": setup_us,
+                               "setup_kernel": ({"kernel": "k_ref8 + k_level_tail (steps 4-6: reference patches, sd coefficients, "
+                                                           "H partials from three sums per patch)",
+                                                 "algorithmic_bytes_per_launch": 24.0 * pix_per_iter * pairs_per_launch,
+                                                 "us_per_launch": float(np.mean(setup_us)),
+                                                 "frac": 24.0 * pix_per_iter * pairs_per_launch / (float(np.mean(setup_us)) * 1e-6) / 8e12,
+                                                 "basis": "HIP events around the level's setup launches in the timed steps"
+                                                          + (" (two streams: they overlap the other engine's iterations)"
+                                                             if overlapping else "")}
+                                                if setup_us and float(np.mean(setup_us)) > 0 else None)}
         pose_fail = False
         if args.cpu_seconds > 0 and world == 1 and not sharded:
             # the same tracking on the CPU path (the oracle: checker and baseline, never the product): problem 0 is

@@ -69,6 +69,11 @@ int ictr_set_device(int device);
 /* measured streaming-read bandwidth of the current GPU in GB/s (bytes >= 1 MiB read reps times with wide loads):
  * the practical HBM ceiling to quote next to the vendor peak in roofline reports */
 int ictr_stream_read_bandwidth(size_t bytes, int reps, double *gbps_out);
+/* inspection: the transposing wave reduction of the resident-iteration kernel alone, on caller data.
+ * vals[64 lanes][64 values], value index = 2 * patch + kind -> out[lane] = sum over the 64 lanes of value
+ * 2 * patch_of_lane[lane] + kind_of_lane[lane] (all host arrays; 64 entries each) */
+int ictr_debug_transpose_reduce(const float *vals, float *out, int *patch_of_lane, int *kind_of_lane,
+                                int patches_per_wave /* 16 or 32: the kernel's two instantiations; 16 uses values 0..31 */);
 
 /* ------------------------------------------------------------------ CamClass (camera.h:19-31, camera.cpp:14-45) */
 typedef struct ictr_cam ictr_cam;

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ictr_device_count": (C.c_int, []),
     "ictr_set_device": (C.c_int, [C.c_int]),
     "ictr_stream_read_bandwidth": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "ictr_debug_transpose_reduce": (C.c_int, [FP, FP, IP, IP, C.c_int]),
     "ictr_cam_create": (C.c_int, [C.POINTER(VP), C.c_int, FP, FP, IP, C.c_int]),
     "ictr_cam_destroy": (None, [VP]),
     "ictr_cam_getfx": (C.c_float, [VP, C.c_int]),

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,11 +44,12 @@ void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
 hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t,
                          const T1Team *);
-hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, int, unsigned, unsigned long long,
-                                 unsigned long long *, int *, hipStream_t);
+hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, int, int, unsigned,
+                                 unsigned long long, unsigned long long *, int *, int, hipStream_t);
+hipError_t launch_debug_transpose_reduce(const float *, float *, int *, int *, int, hipStream_t);
 size_t resident_mail_bytes(int, int);
-int resident_points_per_workgroup(void);
-int resident_blocks_per_cu(void);
+int resident_points_per_workgroup(int);
+int resident_blocks_per_cu(int);
 int track1_team_q(int, int);
 int track1_team_size(int, int);
 size_t track1_team_mail_bytes(int, int);
@@ -128,6 +130,29 @@ extern "C" int ictr_stream_read_bandwidth(size_t bytes, int reps, double *gbps_o
   *gbps_out = (double)bytes * reps / (ms * 1e-3) / 1e9;
   return ICTR_OK;
 }
+// inspection: the resident-iteration kernel's transposing wave reduction alone (ictr_resident.hip, TrAcc) on caller data.
+// vals[64 lanes][64 values = 2 patch + kind] -> out[lane] = the 64-lane sum of value 2 patch_of_lane + kind_of_lane
+extern "C" int ictr_debug_transpose_reduce(const float *vals, float *out, int *patch_of_lane, int *kind_of_lane,
+                                           int patches_per_wave) {
+  if (!vals || !out || !patch_of_lane || !kind_of_lane || (patches_per_wave != 16 && patches_per_wave != 32))
+    return fail(ICTR_ERR_INVALID, "debug_transpose_reduce: bad arguments (patches per wave 16 or 32)");
+  if (int rc = need_device()) return rc;
+  float *dv = nullptr, *dout = nullptr;
+  int *dp = nullptr;
+  hipError_t e = hipMalloc((void **)&dv, sizeof(float) * 64 * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&dout, sizeof(float) * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&dp, sizeof(int) * 128);
+  if (e == hipSuccess) e = hipMemcpy(dv, vals, sizeof(float) * 64 * 64, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_debug_transpose_reduce(dv, dout, dp, dp + 64, patches_per_wave, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(float) * 64, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(patch_of_lane, dp, sizeof(int) * 64, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(kind_of_lane, dp + 64, sizeof(int) * 64, hipMemcpyDeviceToHost);
+  for (void *p : {(void *)dv, (void *)dout, (void *)dp})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) return fail(ICTR_ERR_HIP, "debug_transpose_reduce: %s", hipGetErrorString(e));
+  return ICTR_OK;
+}
+
 static int need_device() {
   if (ictr_device_count() <= 0)
     return fail(ICTR_ERR_NO_DEVICE, "no usable HIP device: the tracker has no CPU fallback");
@@ -1283,54 +1308,79 @@ static int track1_waves(const ictr_batch *b) {
 // With teams of at most 64 workgroups and 256 CUs that is four concurrent launches of the largest team, more of smaller.
 struct TeamFlight {
   hipEvent_t ev;
-  int weight;  // half-CU slots, see team_admit
+  int weight;  // quarter-CU slots, see team_launch
+};
+struct TeamDevice {  // per device: launches in flight (oldest first), recycled events, CU count
+  std::deque<TeamFlight> flights;
+  std::vector<hipEvent_t> events;
+  int n_cu = 0;
 };
 static std::mutex g_team_mu;
-static std::deque<TeamFlight> g_team_flights;   // oldest first
-static std::vector<hipEvent_t> g_team_events;   // recycled events
-static int team_cu_count() {
-  static const int n_cu = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
-      v = 256;
-    return v;
-  }();
-  return n_cu;
+static std::map<int, TeamDevice> g_team_dev;
+static int cu_count_of(int dev) {
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) {
+    (void)hipGetLastError();
+    v = 256;
+  }
+  return v;
 }
-// before the launch: make `s` wait until this launch fits; returns the event to record behind it (team_admit_done)
-// weight, in half-CU slots (two workgroups of the 128-register builds share a CU): a team launch 2 (team - 1) -- its
-// partly resident dispatch front, a whole CU per workgroup --, a resident-iteration launch one per workgroup (ALL of
-// them must be resident). Budget 2 CUs - 2: sum(team - 1) < CUs as before; two resident launches of CUs - 1 workgroups fit.
-static int team_admit(int weight, hipStream_t s, hipEvent_t *ev_out) {
+static int team_cu_count() {  // of the calling thread's current device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = 0;
+  }
   std::lock_guard<std::mutex> lk(g_team_mu);
-  while (!g_team_flights.empty() && hipEventQuery(g_team_flights.front().ev) == hipSuccess) {  // retire finished ones
-    g_team_events.push_back(g_team_flights.front().ev);
-    g_team_flights.pop_front();
+  TeamDevice &d = g_team_dev[dev];
+  if (d.n_cu == 0) d.n_cu = cu_count_of(dev);
+  return d.n_cu;
+}
+// Admit + launch + record as ONE critical section (two host threads driving two engines must not both pass the budget
+// test before either launch is visible): make `s` wait until the launch fits beside the launches in flight on this
+// device, run `launch` (which enqueues the kernel on `s`), record an event behind it and enter it in the flight list.
+// weight, in quarter-CU slots (four workgroups of the resident-iteration kernel share a CU): a team launch
+// 4 (team - 1) -- its partly resident dispatch front, a whole CU per workgroup --, a resident-iteration launch one per
+// workgroup x (4 / workgroups per CU): ALL of them must be resident. Budget 4 CUs - 4: sum(team - 1) < CUs as before;
+// a resident launch that fills every slot but four fits alone.
+template <class F>
+static int team_launch(int weight, hipStream_t s, F &&launch) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = 0;
+  }
+  std::lock_guard<std::mutex> lk(g_team_mu);
+  TeamDevice &d = g_team_dev[dev];
+  if (d.n_cu == 0) d.n_cu = cu_count_of(dev);
+  while (!d.flights.empty() && hipEventQuery(d.flights.front().ev) == hipSuccess) {  // retire finished ones
+    d.events.push_back(d.flights.front().ev);
+    d.flights.pop_front();
   }
   (void)hipGetLastError();  // hipEventQuery's "not ready" is not an error
   int load = 0;
-  for (const TeamFlight &f : g_team_flights) load += f.weight;
+  for (const TeamFlight &f : d.flights) load += f.weight;
   static const int off = env_int("ICTR_TEAM_NO_ADMISSION", 0);  // A/B only: shows what the admission is for
-  const int budget = off ? (1 << 30) : 2 * team_cu_count() - 2;
-  for (size_t i = 0; i < g_team_flights.size() && load + weight > budget; ++i) {
-    HIPCHK(hipStreamWaitEvent(s, g_team_flights[i].ev, 0));  // this launch starts behind flight i
-    load -= g_team_flights[i].weight;
+  const int budget = off ? (1 << 30) : 4 * d.n_cu - 4;
+  for (size_t i = 0; i < d.flights.size() && load + weight > budget; ++i) {
+    HIPCHK(hipStreamWaitEvent(s, d.flights[i].ev, 0));  // this launch starts behind flight i
+    load -= d.flights[i].weight;
   }
   hipEvent_t ev = nullptr;
-  if (!g_team_events.empty()) {
-    ev = g_team_events.back();
-    g_team_events.pop_back();
+  if (!d.events.empty()) {
+    ev = d.events.back();
+    d.events.pop_back();
   } else {
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
-  *ev_out = ev;
-  return ICTR_OK;
-}
-static int team_admit_done(int weight, hipStream_t s, hipEvent_t ev) {
-  std::lock_guard<std::mutex> lk(g_team_mu);
-  HIPCHK(hipEventRecord(ev, s));
-  g_team_flights.push_back(TeamFlight{ev, weight});
+  const int rc = launch();
+  hipError_t er = rc == ICTR_OK ? hipEventRecord(ev, s) : hipSuccess;
+  if (rc != ICTR_OK || er != hipSuccess) {
+    d.events.push_back(ev);  // nothing is in flight behind this event: keep it for the next launch
+    if (rc != ICTR_OK) return rc;
+    return fail(ICTR_ERR_HIP, "team_launch: hipEventRecord failed: %s", hipGetErrorString(er));
+  }
+  d.flights.push_back(TeamFlight{ev, weight});
   return ICTR_OK;
 }
 
@@ -1391,6 +1441,7 @@ static int team_prepare(ictr_batch *b, T1Team *tm) {
 // camera, grid shapes -- all of it goes into the key). Variant bit 15 (32768) keeps the plain launches (A/B).
 struct ResPlan {  // resident-iteration form (below): worker workgroups per frame pair, pairs in flight; 0 = not this form
   int parts = 0, slots = 0;
+  int np = 32;  // patches per wave of the kernel instantiation (32: four 1080p pairs in flight; 16: one or two pairs)
 };
 static ResPlan resident_plan(const ictr_batch *b);
 static bool use_graph(const ictr_batch *b) {
@@ -1441,19 +1492,28 @@ static ResPlan resident_plan(const ictr_batch *b) {
   if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !b->packed)
     return p;
   if (b->maxpts < min_pts || b->op->maxiter < 1) return p;
-  static const int max_b = env_int("ICTR_RESIDENT_MAXB", 8);
+  static const int max_b = env_int("ICTR_RESIDENT_MAXB", 1 << 20);
   if (b->B > max_b && !(v & (1 << 23))) return p;
-  const int bpc = resident_blocks_per_cu();
-  if (bpc < 1) return p;
-  const int q = resident_points_per_workgroup();
-  const int parts = (b->maxpts + q - 1) / q;
-  const int64_t capacity = (int64_t)bpc * team_cu_count();
   static const int max_slots = env_int("ICTR_RESIDENT_SLOTS", 1 << 20);  // experiments: pairs in flight per launch
-  const int slots = (int)std::min<int64_t>(std::min<int64_t>(b->B, max_slots), capacity / (parts + 1));
-  if (slots < 1) return p;
-  if ((int64_t)((b->B + slots - 1) / slots) * b->op->maxiter >= 4000) return p;  // exchange number: 12 bits of the tag
-  p.parts = parts;
-  p.slots = slots;
+  static const int force_np = env_int("ICTR_RESIDENT_NP", 0);             // experiments: 16 or 32
+  // sixteen patches per wave (twice the workgroups, half the patch loop) when ALL pairs of the batch are then in flight
+  // at once; thirty-two (the most templates a CU can hold: four 1080p pairs in flight) otherwise
+  for (int np : {16, 32}) {
+    if (force_np && np != force_np) continue;
+    const int bpc = resident_blocks_per_cu(np);
+    if (bpc < 1) continue;
+    const int q = resident_points_per_workgroup(np);
+    const int parts = (b->maxpts + q - 1) / q;
+    const int64_t capacity = (int64_t)bpc * team_cu_count();
+    const int slots = (int)std::min<int64_t>(std::min<int64_t>(b->B, max_slots), capacity / (parts + 1));
+    if (slots < 1) continue;
+    if (np == 16 && slots < b->B && !force_np) continue;
+    if ((int64_t)((b->B + slots - 1) / slots) * b->op->maxiter >= 4000) return p;  // exchange number: 12 bits of the tag
+    p.parts = parts;
+    p.slots = slots;
+    p.np = np;
+    return p;
+  }
   return p;
 }
 // one level's iterations as ONE resident launch (behind the level's setup launches on the same stream)
@@ -1492,12 +1552,14 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
     return t ? std::max(0.001, atof(t)) : 5.0;
   }();
   // every workgroup of the launch must be resident: it starts when its slots are free of team / resident launches
-  const int weight = p.slots * (p.parts + 1) * (resident_blocks_per_cu() >= 2 ? 1 : 2);
-  hipEvent_t tev = nullptr;
-  if (int rc = team_admit(weight, s, &tev)) return rc;
-  HIPCHK(launch_level_resident(e, lc, level, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
-                               (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, s));
-  return team_admit_done(weight, s, tev);
+  const int bpc = std::max(1, std::min(4, resident_blocks_per_cu(p.np)));
+  const int weight = p.slots * (p.parts + 1) * (4 / bpc);
+  const int mute = (engine_variant(b) & (1 << 25)) ? 1 : 0;  // debug: worker 0 never posts its sums (time-out test)
+  return team_launch(weight, s, [&]() -> int {
+    HIPCHK(launch_level_resident(e, lc, level, p.np, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
+                                 (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, mute, s));
+    return ICTR_OK;
+  });
 }
 
 // split launchers (ictr_kernels.hip): accumulate kernel and tail kernel separately, so that events can bracket
@@ -1574,12 +1636,15 @@ static int enqueue_levels(ictr_batch *b) {
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
     T1Team tm;
     if (int rc = team_prepare(b, &tm)) return rc;
-    hipEvent_t tev = nullptr;
-    if (tm.team > 1)
-      if (int rc = team_admit(2 * (tm.team - 1), b->stream, &tev)) return rc;
-    HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream, tm.team > 1 ? &tm : nullptr));
-    if (tm.team > 1)
-      if (int rc = team_admit_done(2 * (tm.team - 1), b->stream, tev)) return rc;
+    auto launch = [&]() -> int {
+      HIPCHK(launch_track1(e, cams, b->maxpts, track1_waves(b), nullptr, nullptr, b->stream, tm.team > 1 ? &tm : nullptr));
+      return ICTR_OK;
+    };
+    if (tm.team > 1) {
+      if (int rc = team_launch(4 * (tm.team - 1), b->stream, launch)) return rc;
+    } else if (int rc = launch()) {
+      return rc;
+    }
     b->last_team = tm.team;
     b->last_path = 1;
     return ICTR_OK;
@@ -1625,13 +1690,16 @@ static int track_enqueue(ictr_batch *b) {
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
     T1Team tm;
     if (int rc = team_prepare(b, &tm)) return rc;
-    hipEvent_t tev = nullptr;
-    if (tm.team > 1)
-      if (int rc = team_admit(2 * (tm.team - 1), b->stream, &tev)) return rc;
-    HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream,
-                         tm.team > 1 ? &tm : nullptr));
-    if (tm.team > 1)
-      if (int rc = team_admit_done(2 * (tm.team - 1), b->stream, tev)) return rc;
+    auto launch = [&]() -> int {
+      HIPCHK(launch_track1(engine_dev(b), cams, b->maxpts, track1_waves(b), blob, b->d_st_mirror, b->stream,
+                           tm.team > 1 ? &tm : nullptr));
+      return ICTR_OK;
+    };
+    if (tm.team > 1) {
+      if (int rc = team_launch(4 * (tm.team - 1), b->stream, launch)) return rc;
+    } else if (int rc = launch()) {
+      return rc;
+    }
     b->last_team = tm.team;
     b->last_path = 3;
     mirrored = true;

@@ -2,52 +2,53 @@
 // (gfx950 / CDNA4; 8x8 patches, large problems: thousands to tens of thousands of points per frame pair).
 //
 // The per-iteration kernel k_iter8 streams T, Gx, Gy of every patch from HBM in every iteration: 12 of its 16 bytes
-// per pixel, ten times per level, and it runs at the HBM roofline doing so (profiles/r02_notes.md). But a frame pair's
-// templates are only 25 MB per level -- the chip has 128 MB of vector registers and 40 MB of LDS. Here a frame pair is
-// shared by `parts` worker workgroups (128 points each: sixteen patches per wave; Gx and Gy of a patch = two registers
-// of its wave, lane = pixel; T in LDS), which load their templates ONCE per level and keep them for all iterations of
-// odometer.cpp:344-418; an iteration then reads only the current frame's windows (cache-resident) and exchanges 12
-// numbers per workgroup:
+// per pixel, ten times per level, and it runs at the HBM roofline doing so. But a frame pair's templates are only 25 MB
+// per level -- the chip has 128 MB of vector registers and 40 MB of LDS. Here a frame pair is shared by `parts` worker
+// workgroups that load their templates ONCE per level and keep them for all iterations of odometer.cpp:344-418; an
+// iteration then reads only the current frame's windows (cache-resident) and exchanges six numbers per workgroup.
 //
-//   every workgroup   stage 1  one point per lane (lanes 0-15 of a wave): projection at the current pose
-//                              (pose.cpp:384-391), ind_new (odometer.cpp:369-377), bilinear weights + window offset
-//                     stage 2  sixteen patches per wave from registers: current-frame window (utilities.cpp:55-113),
-//                              residual, J^T r (odometer.cpp:381-404) in six per-lane accumulators
-//                     gather   the workgroup's six sums (as hi/lo float pairs) -> the pair's mailbox
-//   the pair's solver workgroup (no templates: its registers never compete with the resident ones)
-//                     all eight waves poll the mailbox (32 workers each, one round trip), fixed-order f64 sum, then
-//                     ONE wave: substitution with the level's LU factors, pose update, exp map, loop condition
-//                     (odometer.cpp:407-418, 509-515; WaveSolver, ictr_devfn.h) -> broadcast of cpos_G + loop flag
-//   every worker      polls the broadcast, next iteration
-//
-// Two hops per iteration instead of two kernel boundaries and 33 MB of HBM traffic per pair. An iteration is a serial
-// chain of ~9.4 us for ONE pair (tools/resprof.py), so `slots` pairs are in flight at once (two workgroups per CU, 128
-// registers each) and the chains of different pairs overlap on the same SIMDs (two in flight: +10 % per chain); every
-// slot walks through its share of the batch's pairs. Measured: one 1080p pair 0.42 ms against 0.72 with the streaming
-// kernels; the default for up to 8 pairs per engine (ictr_host.hip, resident_plan).
+// r03 form (what bounds this kernel is the number of frame pairs in flight -- an iteration is a latency chain of two
+// hops through memory -- so the design maximises the templates a CU holds):
+//   * a worker workgroup = 4 waves, a wave keeps THIRTY-TWO patches: Gx and Gy of a patch are two registers of the wave
+//     (lane = pixel; 64 of its 128 registers), T sits in LDS (32 KB per workgroup); four workgroups per CU = 512 points
+//     = 384 KB of templates per CU, FOUR 1080p frame pairs in flight on the chip (r02: two);
+//   * J is constant over a patch (odometer.cpp:313-326), so b_k = sum_px sd_k r = sum_patches [cx_k A + cy_k B] with the
+//     two per-patch sums A = sum Gx r, B = sum Gy r: per pixel the loop does the bilinear blend, the residual and two
+//     products; the 64 per-lane values (A, B of 32 patches) are summed over the 64 lanes by a TRANSPOSING reduction
+//     (each merge halves the registers and doubles the lanes summed: two instructions per value) that leaves lane l
+//     with the complete sum of one (patch, A|B); the lane then applies ITS point's six coefficients -- no per-patch
+//     coefficient broadcast, no per-pixel multiply-adds into six sums;
+//   * the workgroup's six partial sums travel as six float granules (the precision of the streaming form's float
+//     partials); the pair's SOLVER workgroup polls them in one round trip (256 lanes x 8 granules), adds in a fixed
+//     order in f64, one wave runs the solver turn (WaveSolver, ictr_devfn.h: substitution with the level's LU factors,
+//     pose update, exp map, loop condition; odometer.cpp:407-418, 509-515) and broadcasts cpos_G + the loop flag.
 // The mailbox protocol is the one of the team form (ictr_track1.hip "Teams"): 8-byte granules {float bits, tag},
 // tags = launch epoch << 12 | exchange number, double-buffered by parity, bounded polling with a sticky error flag.
-// H is accumulated by the level's setup launch (k_ref8<.., WH = true, PK = true>: per-workgroup partials) and reduced +
-// factored by the pair's solver workgroup at the start of the pair (what k_level_tail does in the other launch forms),
-// the templates and the (possibly stale) coefficients come from the buffers that launch wrote: patches, coefficients and
-// projections are bit-identical to the other launch forms, b differs by summation order only.
+// H partials come from the level's setup launch (k_ref8: three sums per patch) and are reduced + factored by the pair's
+// solver workgroup at the start of the pair (what k_level_tail does in the other launch forms); templates and (possibly
+// stale) coefficients come from the buffers that launch wrote: patches, coefficients and projections are bit-identical
+// to the other launch forms, b differs by summation order only.
+#include <type_traits>
+
 #include "ictr_dev.h"
 #include "ictr_devfn.h"
 #include "se3_math.h"
 
 namespace ictr {
 
-constexpr int kResWaves = 8;          // waves per workgroup
-constexpr int kResPPW = 16;           // patches (points) per wave
-constexpr int kResQ = kResWaves * kResPPW;  // points per workgroup
-constexpr int kResSlot = 16;          // granules per workgroup in the gather box (12 used)
-constexpr int kGxL = 0;               // patches per wave whose Gx lives in LDS instead of a register (experiments)
+constexpr int kResWaves = 4;                // waves per workgroup
+constexpr int kResThreads = 64 * kResWaves;
+// patches (points) per wave: template parameter NP of the kernel, 32 (large batches: four pairs in flight) or 16 (one
+// or two pairs: twice the workgroups, half the patch loop); points per workgroup = kResWaves * NP
+constexpr int kResSlot = 8;                 // granules per worker workgroup in the gather box (6 used)
+constexpr int kResD = 4;                    // current-frame windows in flight per wave (4 registers each)
 
 struct ResArgs {
   LevelCam lc;
   int level;
   int parts, slots;          // worker workgroups per frame pair; pairs in flight (grid = slots * (parts + 1))
   int nblk;                  // workgroups per problem of the level's setup launch (their H partials: e.partH)
+  int dbg_mute;              // debug (variant bit 25): worker `dbg_mute - 1` never posts its sums (time-out test); 0 = off
   unsigned tag0;             // launch epoch << 12
   unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
   unsigned long long *mail;  // per slot: gather box [2][parts][kResSlot], then broadcast box [2][16]
@@ -55,11 +56,6 @@ struct ResArgs {
 };
 
 __device__ __forceinline__ size_t res_slot_granules(int parts) { return (size_t)2 * parts * kResSlot + 2 * 16; }
-
-__device__ __forceinline__ double res_gather64(double v, int src_lane) {
-  const int lo = lane_gather(__double2loint(v), src_lane), hi = lane_gather(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
 
 struct ResPoll {
   unsigned long long limit;
@@ -96,6 +92,165 @@ __device__ __forceinline__ void res_poll(ResPoll &pc, const unsigned long long *
     RES_EACH8(RES_RELOAD)
   }
 }
+// one granule per lane (the workers' wait for the broadcast)
+__device__ __forceinline__ unsigned long long res_poll1(ResPoll &pc, const unsigned long long *src, unsigned tag, int lane) {
+  unsigned long long g = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag << 32;
+  if (pc.dead) return g;
+  bool started = false;
+  unsigned long long t0 = 0;
+  while (__builtin_amdgcn_ballot_w64((unsigned)(g >> 32) != tag) != 0) {
+    if (!started) {
+      t0 = wall_clock64();
+      started = true;
+    } else if (wall_clock64() - t0 > pc.limit) {
+      if (lane == 0) __hip_atomic_store(pc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      pc.dead = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if ((unsigned)(g >> 32) != tag) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return g;
+}
+
+// ---------------------------------------------------------------- transposing wave reduction
+// merge(u, v) on lane bit k: the lanes with bit k = 0 end up with u summed over the lane pair {l, l ^ (1 << k)}, the
+// lanes with bit k = 1 with v summed over the same pair. Six levels of merges (one per lane bit) take 64 per-lane
+// values to ONE register in which every lane holds the complete 64-lane sum of one of the values.
+//   bits 2, 3: two DPP adds, each writing half of the banks (row_shl / row_shr by 4 or 8 with a bank mask);
+//   bits 4, 5: v_permlane16_swap / v_permlane32_swap (gfx950) + one add;  bits 0, 1: quad permutes + select.
+// (inline DPP: the s_nop covers the "VALU write -> DPP read" hazard, which the compiler cannot see inside asm)
+__device__ __forceinline__ float tr_merge_b2(float u, float v) {
+  float w;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "=v"(w) : "v"(u));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(w) : "v"(v));
+  return w;
+}
+__device__ __forceinline__ float tr_merge_b3(float u, float v) {
+  float w;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3" : "=v"(w) : "v"(u));
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(w) : "v"(v));
+  return w;
+}
+// (inline asm: with ROCm 7.2's hipcc the two results of __builtin_amdgcn_permlane16/32_swap come back as the SAME register
+// -- "v_permlane16_swap v25, v26; v_add_f32 v6, v25, v25" -- found by tests/test_gpu_parity.py's reduction test; the
+// s_nops cover the VALU-write -> permlane-swap hazard on both sides, which the compiler cannot see inside asm)
+__device__ __forceinline__ float tr_merge_b4(float u, float v) {  // rows (16 lanes): [u0 u1 u2 u3],[v0..] -> [u0+u1, v0+v1, u2+u3, v2+v3]
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(u), "+v"(v));  // odd rows of u <-> even rows of v
+  return u + v;
+}
+__device__ __forceinline__ float tr_merge_b5(float u, float v) {  // halves: -> [u_lo + u_hi, v_lo + v_hi]
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(u), "+v"(v));  // upper half of u <-> lower half of v
+  return u + v;
+}
+__device__ __forceinline__ float tr_merge_b0(float u, float v, int lane) {
+  const float t = u + dpp_mov<0xB1>(u), s = v + dpp_mov<0xB1>(v);
+  return (lane & 1) ? s : t;
+}
+__device__ __forceinline__ float tr_merge_b1(float u, float v, int lane) {
+  const float t = u + dpp_mov<0x4E>(u), s = v + dpp_mov<0x4E>(v);
+  return (lane & 2) ? s : t;
+}
+// level L = 1..5 of the reduction tree over a wave's 32 patches (level 0 = the patch's own (A, B) pair on lane bit 2)
+template <int L>
+__device__ __forceinline__ float tr_merge_level(float u, float v, int lane) {
+  if constexpr (L == 1) return tr_merge_b3(u, v);
+  if constexpr (L == 2) return tr_merge_b4(u, v);
+  if constexpr (L == 3) return tr_merge_b5(u, v);
+  if constexpr (L == 4) return tr_merge_b0(u, v, lane);
+  return tr_merge_b1(u, v, lane);
+}
+// which patch of the wave and which of its two sums (0: A = sum Gx r, 1: B = sum Gy r) lane l holds at the end. NP = 32:
+// all six lane bits are consumed by merges; NP = 16: the last bit (1) is summed plainly, so lane pairs {l, l ^ 2} hold the
+// same sum and only the lanes with bit 1 clear ("primary") may contribute it
+template <int NP>
+__device__ __forceinline__ int tr_patch_of_lane(int l) {
+  const int p = ((l >> 3) & 1) | (((l >> 4) & 1) << 1) | (((l >> 5) & 1) << 2) | ((l & 1) << 3);
+  return NP == 32 ? (p | (((l >> 1) & 1) << 4)) : p;
+}
+__device__ __forceinline__ int tr_kind_of_lane(int l) { return (l >> 2) & 1; }
+template <int NP>
+__device__ __forceinline__ bool tr_primary_lane(int l) { return NP == 32 ? true : ((l & 2) == 0); }
+// the binary counter of pending registers: push<J>(A, B) takes patch J's pair of per-lane values (J = 0..NP-1 in order);
+// after push<NP-1> `F` holds, in lane l, the 64-lane sum of (A if kind == 0 else B) of patch tr_patch_of_lane<NP>(l)
+template <int NP>
+struct TrAcc {
+  static_assert(NP == 32 || NP == 16, "patches per wave");
+  float p1, p2, p3, p4, p5, F;
+  template <int J>
+  __device__ __forceinline__ void push(float A, float B, int lane) {
+    float m = tr_merge_b2(A, B);
+    if constexpr ((J & 1) == 0) {
+      p1 = m;
+    } else {
+      m = tr_merge_level<1>(p1, m, lane);
+      if constexpr ((J & 2) == 0) {
+        p2 = m;
+      } else {
+        m = tr_merge_level<2>(p2, m, lane);
+        if constexpr ((J & 4) == 0) {
+          p3 = m;
+        } else {
+          m = tr_merge_level<3>(p3, m, lane);
+          if constexpr ((J & 8) == 0) {
+            p4 = m;
+          } else {
+            m = tr_merge_level<4>(p4, m, lane);
+            if constexpr (NP == 16) {
+              F = m + dpp_mov<0x4E>(m);  // lane bit 1: plain sum
+            } else if constexpr ((J & 16) == 0) {
+              p5 = m;
+            } else {
+              F = tr_merge_level<5>(p5, m, lane);
+            }
+          }
+        }
+      }
+    }
+  }
+};
+template <int NP, int J, class Fn>
+__device__ __forceinline__ void tr_for_each_patch(Fn &&fn) {  // fn(integral_constant<J>) for J = 0..NP-1, in order
+  if constexpr (J < NP) {
+    fn(std::integral_constant<int, J>{});
+    tr_for_each_patch<NP, J + 1>(fn);
+  }
+}
+
+// inspection (tests/test_gpu_parity.py): the reduction alone on caller data, vals[lane][2 patch + kind]
+template <int NP>
+__global__ __launch_bounds__(64) void k_debug_transpose_reduce(const float *__restrict__ vals, float *__restrict__ out,
+                                                               int *__restrict__ patch_of_lane, int *__restrict__ kind_of_lane) {
+  const int lane = threadIdx.x;
+  TrAcc<NP> acc;
+  tr_for_each_patch<NP, 0>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    acc.template push<j>(vals[lane * 64 + 2 * j], vals[lane * 64 + 2 * j + 1], lane);
+  });
+  out[lane] = acc.F;
+  patch_of_lane[lane] = tr_patch_of_lane<NP>(lane);
+  kind_of_lane[lane] = tr_kind_of_lane(lane);
+}
+hipError_t launch_debug_transpose_reduce(const float *vals, float *out, int *pl, int *kl, int np, hipStream_t s) {
+  if (np == 16)
+    hipLaunchKernelGGL(k_debug_transpose_reduce<16>, dim3(1), dim3(64), 0, s, vals, out, pl, kl);
+  else
+    hipLaunchKernelGGL(k_debug_transpose_reduce<32>, dim3(1), dim3(64), 0, s, vals, out, pl, kl);
+  return hipGetLastError();
+}
+
+// sum of a double over aligned groups of eight lanes (every lane of the group gets it)
+__device__ __forceinline__ double res_sum8(double v) {
+#define RES_DPP64(ctrl)                                                                              \
+  {                                                                                                  \
+    const int lo = dpp_mov<ctrl>(__double2loint(v)), hi = dpp_mov<ctrl>(__double2hiint(v));          \
+    v += __hiloint2double(hi, lo);                                                                   \
+  }
+  RES_DPP64(0xB1)   // quad_perm [1,0,3,2]
+  RES_DPP64(0x4E)   // quad_perm [2,3,0,1]
+  RES_DPP64(0x141)  // row_half_mirror: the other quad of the group (its lanes all hold that quad's sum)
+  return v;
+}
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #ifdef ICTR_RES_PROF  // diagnostic builds only: per-phase cycle counters of one wave (tools/resprof.py)
@@ -112,24 +267,19 @@ struct ResWin {
   f32x2_a4 ab, cd;  // (x-1,y),(x,y) and (x-1,y-1),(x,y-1)
 };
 
-// Register budget: 128 per wave = two workgroups per CU. Gx and Gy of a wave's sixteen patches live in registers (32),
-// T in LDS (32 KB per workgroup). An iteration is a latency chain and the chains of the pairs in flight overlap almost
-// perfectly (two in flight cost 10 % per chain), so pairs in flight = throughput -- but a CU cannot hold a third pair's
-// share: a build for 80 registers (three workgroups per CU; T and five patches' Gx in LDS, kGxL = 5, two windows in
-// flight) spills in the solver and in the patch loop and was SLOWER (7.1 against 6.5 ms per 32 pairs,
-// profiles/r02_notes.md).
-__global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev e, ResArgs a) {
-  __shared__ __attribute__((aligned(16))) float4 sRec[kResWaves][kResPPW * 4];  // per point [w1 w0 w3 w2][cx2..5][cy2..5][cx0 cy1 vis -]
-  __shared__ float sT[kResWaves][(kResPPW + kGxL) * 64];  // T of the wave's patches, then Gx of the first kGxL (lane = pixel)
+// Register budget: 128 per wave = four 4-wave workgroups per CU (launch bounds), 64 of them Gx / Gy of the wave's patches.
+template <int NP>
+__global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, ResArgs a) {
+  constexpr int kResPPW = NP, kResQ = kResWaves * NP;
+  __shared__ __attribute__((aligned(16))) float4 sRecW[kResWaves][kResPPW];  // per point: bilinear weights [w1 w0 w3 w2]
+  __shared__ float sT[kResWaves][kResPPW * 64];  // T of the wave's patches (lane = pixel)
   __shared__ float sPart[kResWaves][8];
   __shared__ double sRed[kResWaves][8];
-  __shared__ float sG[16];  // cpos_G of the current iteration, [12] = loop flag (bits)
-  __shared__ ProbState sSt; // solver workgroup: the problem's state between the solver's turns
+  __shared__ float sG[16];   // cpos_G of the current iteration, [12] = loop flag (bits)
+  __shared__ ProbState sSt;  // solver workgroup: the problem's state between the solver's turns
 
-  // a pair's workgroups: `parts` workers (128 points each) + ONE solver workgroup (index parts) that holds no templates,
-  // so the solver's registers and the sixteen resident patches never compete
   const int parts = a.parts;
-  const int group = parts + 1;
+  const int group = parts + 1;  // a pair's workgroups: `parts` workers (128 points each) + ONE solver workgroup (index parts)
   const int slot = (int)blockIdx.x / group;
   const int part = (int)blockIdx.x - slot * group;
   const int tid = threadIdx.x;
@@ -151,7 +301,7 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
     // ================================================================ the pair's solver workgroup
     SolveOpts sopt = solve_opts(e);
     sopt.robust = 0;
-    __shared__ double sRedH[64 * kResWaves / 32][32];
+    __shared__ double sRedH[kResThreads / 32][32];
     __shared__ float sH[32];
     for (int b = slot; b < e.B; b += a.slots) {
       const ProbState &gst = e.st[b];
@@ -161,10 +311,10 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
       {
         const unsigned *src = reinterpret_cast<const unsigned *>(&gst);
         unsigned *dst = reinterpret_cast<unsigned *>(&sSt);
-        for (int i = tid; i < (int)(sizeof(ProbState) / 4); i += blockDim.x) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(ProbState) / 4); i += kResThreads) dst[i] = src[i];
       }
       // ---- what k_level_tail does in the other launch forms: fixed-order f64 sum of the setup launch's H partials
-      // (16 slices x 32 components, then the slices in order), full-pivot LU once per level, loop state reset --
+      // (8 slices x 32 components, then the slices in order), full-pivot LU once per level, loop state reset --
       // while the pair's workers load their templates
       {
         const int j = tid & 31, sl = tid >> 5;
@@ -172,7 +322,7 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
         const float *ph = e.partH + (size_t)b * a.nblk * kPartHStride + j;
         if (j < kHUnique) {
 #pragma unroll 8
-          for (int k = sl; k < a.nblk; k += 64 * kResWaves / 32) sacc += (double)ph[(size_t)k * kPartHStride];
+          for (int k = sl; k < a.nblk; k += kResThreads / 32) sacc += (double)ph[(size_t)k * kPartHStride];
         }
         sRedH[sl][j] = sacc;
       }
@@ -180,7 +330,7 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
       if (tid < kHUnique) {
         double sacc = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < 64 * kResWaves / 32; ++sl) sacc += sRedH[sl][tid];
+        for (int sl = 0; sl < kResThreads / 32; ++sl) sacc += sRedH[sl][tid];
         sH[tid] = (float)sacc;
       }
       __syncthreads();
@@ -191,46 +341,32 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
         if (lane == 0) level_reset(sSt, e);
       }
       __syncthreads();
-      if (!active) {  // nothing to iterate: the state (H, factors, reset loop state) still goes back
-        if (wave == 0) {
-          const unsigned *src = reinterpret_cast<const unsigned *>(&sSt);
-          unsigned *dst = reinterpret_cast<unsigned *>(e.st + b);
-          for (int i = lane; i < (int)(sizeof(ProbState) / 4); i += 64) dst[i] = src[i];
-        }
-        __syncthreads();
-        continue;
-      }
       while (active) {
         seq += 1;
         const unsigned tag = a.tag0 + seq;
         const unsigned long long *gslot = gbox + (size_t)(seq & 1u) * parts * kResSlot;
         unsigned long long *bslot = bbox + (size_t)(seq & 1u) * 16;
-        // every wave sums a share of the workers: lane (rr, k) reads value k of the workers rr, rr + 4, ... of the
-        // share, eight granule loads in flight per lane (32 workers per round trip and wave)
+        // lane (k, rr) = 8 k + rr (k < 6) reads value k of the workers ((8 wave + u) 8 + rr), u = 0..7: eight granule
+        // loads in flight per lane, 256 workers per round trip; sums in a fixed order: u, rounds, rr, waves
         RES_MARK(0)  // solver: loop overhead / barrier behind the previous broadcast
-        const int k = lane & 15, rr = lane >> 4;
-        const int per_wave = (parts + kResWaves - 1) / kResWaves;
-        const int p_lo = wave * per_wave, p_hi = min(parts, p_lo + per_wave);
+        const int k = lane >> 3, rr = lane & 7;
         double accd = 0.0;
-        for (int r0 = p_lo; r0 < p_hi; r0 += 32) {
+        for (int r0 = 0; r0 < parts; r0 += 64 * kResWaves) {
           const unsigned long long *src[8];
           unsigned long long g[8];
-#define RES_SRC(u)                                                                  \
-  {                                                                                 \
-    const int r = r0 + u * 4 + rr;                                                  \
-    src[u] = (k < 12 && r < p_hi) ? gslot + (size_t)r * kResSlot + k : nullptr;    \
+#define RES_SRC(u)                                                                   \
+  {                                                                                  \
+    const int r = r0 + (wave * 8 + u) * 8 + rr;                                      \
+    src[u] = (k < 6 && r < parts) ? gslot + (size_t)r * kResSlot + k : nullptr;      \
   }
           RES_EACH8(RES_SRC)
           res_poll(pc, src, g, tag, lane);
 #define RES_ACC(u) accd += (double)__builtin_bit_cast(float, (unsigned)(g[u] & 0xffffffffu));
           RES_EACH8(RES_ACC)
         }
-        double tot = accd;
-#pragma unroll
-        for (int j = 1; j < 4; ++j) tot += res_gather64(accd, j * 16 + k);
-        tot += res_gather64(tot, (lane + 6) & 63);  // hi + lo (meaningful in lanes 0-5)
+        const double tot = res_sum8(accd);
         RES_MARK(1)  // solver: waiting for / summing the workers' granules
-        if (lane < 6) sRed[wave][lane] = tot;
+        if (rr == 0 && k < 6) sRed[wave][k] = tot;
         __syncthreads();
         RES_MARK(2)  // solver: barrier
         if (wave == 0) {
@@ -258,7 +394,7 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
         __syncthreads();
         active = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sG[12]));
       }
-      if (wave == 0) {  // final state of the level back to the problem's record
+      if (wave == 0) {  // final state of the level (H, factors, pose, loop state) back to the problem's record
         const unsigned *src = reinterpret_cast<const unsigned *>(&sSt);
         unsigned *dst = reinterpret_cast<unsigned *>(e.st + b);
         for (int i = lane; i < (int)(sizeof(ProbState) / 4); i += 64) dst[i] = src[i];
@@ -277,7 +413,10 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
   const int sw = lc.sw;
   const unsigned off_cd = (unsigned)((lane >> 3) * sw + (lane & 7)) * 4u;  // bytes from the window's top-left texel
   const unsigned off_ab = off_cd + (unsigned)sw * 4u;
-  float4 *const recs = sRec[wave];
+  float4 *const recs = sRecW[wave];
+  float *const tw = sT[wave] + lane;
+  const int my_patch = tr_patch_of_lane<NP>(lane);  // the (patch, A|B) whose complete sum this lane holds after stage 2
+  const int my_kind = tr_kind_of_lane(lane);
   for (int b = slot; b < e.B; b += a.slots) {
     const ProbState &gst = e.st[b];
     const int npts = gst.npts;
@@ -285,61 +424,63 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
     if (!active) continue;
     const int i0 = part * kResQ + wave * kResPPW;
     const int cnt = min(kResPPW, max(0, npts - i0));  // this wave's points (wave-uniform)
-    const PlaneSet pl = e.planes[b * e.nlev + a.level];
+    // (the plane pointer is wave-uniform, but it comes out of a table in memory: say so, or every buffer load below is
+    // wrapped in a waterfall loop over its descriptor)
+    const float *cur_plane;
+    {
+      const unsigned long long pc64 = reinterpret_cast<unsigned long long>(e.planes[b * e.nlev + a.level].cur);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pc64), hi = __builtin_amdgcn_readfirstlane((unsigned)(pc64 >> 32));
+      cur_plane = reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+    }
     const __amdgpu_buffer_rsrc_t rcur =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl.cur), 0, 0x7fffffff, 0x00020000);
-    // ---- templates of this wave's patches into registers (written by the level's setup launch; stale ones included)
-    float Gx[kResPPW - kGxL], Gy[kResPPW];
-    float *const tw = sT[wave] + lane;
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cur_plane), 0, 0x7fffffff, 0x00020000);
+    // ---- templates of this wave's patches (written by the level's setup launch; stale ones included): Gx, Gy into
+    // registers, T into LDS
+    float Gx[kResPPW], Gy[kResPPW];
     {
       const float *gT = e.T + ((size_t)b * M + i0) * 64 + lane;
       const float *gGx = e.Gx + ((size_t)b * M + i0) * 64 + lane;
       const float *gGy = e.Gy + ((size_t)b * M + i0) * 64 + lane;
 #pragma unroll
       for (int j = 0; j < kResPPW; ++j) {
-        float t = 0.0f, gx = 0.0f;
+        float t = 0.0f;
+        Gx[j] = 0.0f;
         Gy[j] = 0.0f;
         if (j < cnt) {
           t = __builtin_nontemporal_load(gT + j * 64);
-          gx = __builtin_nontemporal_load(gGx + j * 64);
+          Gx[j] = __builtin_nontemporal_load(gGx + j * 64);
           Gy[j] = __builtin_nontemporal_load(gGy + j * 64);
         }
         tw[j * 64] = t;
-        if (j < kGxL)
-          tw[(kResPPW + j) * 64] = gx;
-        else
-          Gx[j - kGxL] = gx;
+        if ((j & 7) == 7) asm volatile("" ::: "memory");  // eight patches' T in flight at a time (they only pass through)
       }
     }
-    // ---- this lane's point (lanes 0-15): X, Y, Z stay in registers, the level's coefficients go into the record
+    // ---- lane l < 32: point i0 + l (X, Y, Z stay in registers). Every lane: the six coefficients of ITS (patch, A|B):
+    // cx_k of point my_patch for an A lane, cy_k for a B lane (odometer.cpp:313-326; zeros beyond the wave's points)
     const bool pv = lane < cnt;
     float X = 0.0f, Y = 0.0f, Z = 1.0f;
-    if (lane < kResPPW) {
-      float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-      if (pv) {
-        const int ip = i0 + lane;
-        const float *p3 = e.pt3d + (size_t)b * 3 * M;
-        X = p3[ip], Y = p3[ip + M], Z = p3[ip + 2 * M];
-        const float4 *c4 = reinterpret_cast<const float4 *>(e.coef + ((size_t)b * M + ip) * kCoefStride);
-        q0 = c4[0], q1 = c4[1], q2 = c4[2];  // cx0..3 | cx4 cx5 cy0 cy1 | cy2..5
-      }
-      float4 *r4 = recs + lane * 4;
-      r4[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      r4[1] = make_float4(q0.z, q0.w, q1.x, q1.y);  // cx2 cx3 cx4 cx5
-      r4[2] = make_float4(q2.x, q2.y, q2.z, q2.w);  // cy2 cy3 cy4 cy5
-      r4[3] = make_float4(q0.x, q1.w, 0.0f, 0.0f);  // cx0 cy1 vis -
+    if (pv) {
+      const float *p3 = e.pt3d + (size_t)b * 3 * M;
+      X = p3[i0 + lane], Y = p3[i0 + lane + M], Z = p3[i0 + lane + 2 * M];
+    }
+    float c6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (my_patch < cnt && tr_primary_lane<NP>(lane)) {
+      const float *cl = e.coef + ((size_t)b * M + i0 + my_patch) * kCoefStride + (my_kind ? 6 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = cl[k];
     }
     if (tid < 12) sG[tid] = gst.G[tid];
     __syncthreads();
 
     while (active) {  // uniform over the pair's workgroups: every one of them follows the same broadcast
       RES_MARK(0)  // worker: barrier behind the broadcast
-      float Gc[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) Gc[k] = sG[k];
-      // ---- stage 1 (pose.cpp:384-391, odometer.cpp:369-377)
-      int base_v = 0;
+      // ---- stage 1 (pose.cpp:384-391, odometer.cpp:369-377): lane l < 32 <-> point i0 + l
+      int base_v;
+      float vis_f;
       {
+        float Gc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Gc[k] = sG[k];
         const float tx = Gc[0] * X + Gc[1] * Y + Gc[2] * Z + Gc[3];
         const float ty = Gc[4] * X + Gc[5] * Y + Gc[6] * Z + Gc[7];
         const float tz = Gc[8] * X + Gc[9] * Y + Gc[10] * Z + Gc[11];
@@ -348,81 +489,74 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
         const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
         const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
         base_v = ((tp.row0 - 1) * sw + tp.col0 - 1) * 4;                 // bytes: the buffer load's scalar offset
-        if (lane < kResPPW) {
-          recs[lane * 4] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
-          reinterpret_cast<float *>(recs + lane * 4 + 3)[2] = vis ? 1.0f : 0.0f;
-        }
+        vis_f = vis ? 1.0f : 0.0f;
+        if (lane < kResPPW) recs[lane] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       RES_MARK(1)  // worker: stage 1
-      // ---- stage 2: sixteen patches from registers, the windows of four patches in flight
-      f32x2_t acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}, acc45 = {0.0f, 0.0f};
-      constexpr int kD = 4;  // windows in flight (registers: 4 each)
-      ResWin W[kD];
+      // ---- stage 2: thirty-two patches from registers, kResD windows in flight. Per pixel: blend (utilities.cpp:107,
+      // reference operand order, not contracted), residual (odometer.cpp:381), Gx r and Gy r; the per-patch sums by the
+      // transposing reduction: a patch's (A, B) pair merges on lane bit 2, then a binary counter of pending registers
+      ResWin W[kResD];
       auto issue = [&](int j) {
         const int soff = rlane(base_v, j);
-        W[j % kD].cd = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_cd, soff, 0));
-        W[j % kD].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_ab, soff, 0));
+        W[j % kResD].cd = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_cd, soff, 0));
+        W[j % kResD].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_ab, soff, 0));
       };
 #pragma unroll
-      for (int j = 0; j < kD; ++j) issue(j);
-#pragma unroll
-      for (int j = 0; j < kResPPW; ++j) {
-        if ((j & 3) == 0 && j >= cnt) break;  // wave-uniform: whole groups of four behind the wave's last point
-        // (compiler barrier tied to the sums: the next patch's record reads stay behind this patch's arithmetic)
-        asm volatile("" : "+v"(acc01), "+v"(acc23), "+v"(acc45) : : "memory");
-        const float4 *r4 = recs + j * 4;
-        const float4 wv = r4[0], qx = r4[1], qy = r4[2], qz = r4[3];
-        const ResWin w = W[j % kD];
-        if (j + kD < kResPPW) issue(j + kD);
-        // utilities.cpp:107 in the reference's operand order, not contracted: ((w0 a + w1 b) + w2 c) + w3 d
+      for (int j = 0; j < kResD; ++j) issue(j);
+      TrAcc<NP> acc;
+      float4 wv_n = recs[0];  // the next patch's weights and T: one patch ahead of the arithmetic (LDS latency hidden)
+      float t_n = tw[0];
+      tr_for_each_patch<NP, 0>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float4 wv = wv_n;
+        const float t = t_n;
+        asm volatile("" ::: "memory");  // (the LDS reads of later patches stay behind this point: two patches' worth live)
+        if constexpr (j + 1 < kResPPW) {
+          wv_n = recs[j + 1];
+          t_n = tw[(j + 1) * 64];
+        }
+        const ResWin w = W[j % kResD];
         const float inew = wv.y * w.ab.y + wv.x * w.ab.x + wv.w * w.cd.y + wv.z * w.cd.x;
-        const float r = (tw[j * 64] - inew) * qz.z;  // pdiff (odometer.cpp:381); 0 out of the new view and for padding
-        const float gxj = j < kGxL ? tw[(kResPPW + j) * 64] : Gx[j < kGxL ? 0 : j - kGxL];
-        const f32x2_t g2 = {gxj * r, Gy[j] * r}, gr2 = {g2.x, g2.x}, hr2 = {g2.y, g2.y};
-        acc01 = __builtin_elementwise_fma(g2, (f32x2_t){qz.x, qz.y}, acc01);  // sd1 = Gx cx0, sd2 = Gy cy1
-        acc23 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.x, qx.y},         // sd3..sd6 = Gx cxk + Gy cyk
-                                          __builtin_elementwise_fma(hr2, (f32x2_t){qy.x, qy.y}, acc23));
-        acc45 = __builtin_elementwise_fma(gr2, (f32x2_t){qx.z, qx.w},         // (odometer.cpp:319-326)
-                                          __builtin_elementwise_fma(hr2, (f32x2_t){qy.z, qy.w}, acc45));
-      }
+        if constexpr (j + kResD < kResPPW) issue(j + kResD);
+        const float r = t - inew;  // pdiff (odometer.cpp:381); visibility is applied to the patch sums below
+        acc.template push<j>(Gx[j] * r, Gy[j] * r, lane);
+      });
+      const float F = acc.F;
       RES_MARK(2)  // worker: stage 2
+      // ---- lane = (patch, A|B): its point's visibility and coefficients, then the six sums over the wave
       {
-        const float accs[6] = {acc01.x, acc01.y, acc23.x, acc23.y, acc45.x, acc45.y};
+        const float val = F * lane_gather(vis_f, my_patch);  // 0 out of the new view (ind_new) and beyond the wave's points
         float o = 0.0f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          const float v = wave_sum_dpp(accs[k]);
+          const float v = wave_sum_dpp(c6[k] * val);  // b_k = sum_patches cx_k A + cy_k B (odometer.cpp:386-404)
           o = lane == k ? v : o;
         }
         if (lane < 6) sPart[wave][lane] = o;
       }
       __syncthreads();
       RES_MARK(3)  // worker: wave reduction + barrier
-      // ---- gather: the workgroup's six sums as (hi, lo) float pairs -> the pair's mailbox; then the broadcast
+      // ---- gather: the workgroup's six sums -> the pair's mailbox; then the broadcast
       seq += 1;
       const unsigned tag = a.tag0 + seq;
       unsigned long long *gslot = gbox + (size_t)(seq & 1u) * parts * kResSlot;
       const unsigned long long *bslot = bbox + (size_t)(seq & 1u) * 16;
       if (wave == 0) {
-        double bs = 0.0;
-        if (lane < 6)
-          for (int w = 0; w < kResWaves; ++w) bs += (double)sPart[w][lane];
-        const float hi = (float)bs;
-        const float lo = (float)(bs - (double)hi);
-        const float pvv = lane < 6 ? hi : lane_gather(lo, lane - 6);
-        if (lane < 12)
-          __hip_atomic_store(gslot + (size_t)part * kResSlot + lane,
-                             ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pvv),
+        int lane_v = lane;  // (opaque copy: the two mailbox addresses are formed here, not kept in registers over the loop)
+        asm volatile("" : "+v"(lane_v));
+        float bs = 0.0f;
+        if (lane < 6) bs = (sPart[0][lane] + sPart[1][lane]) + (sPart[2][lane] + sPart[3][lane]);
+        if (lane < 6 && part + 1 != a.dbg_mute)
+          __hip_atomic_store(gslot + (size_t)part * kResSlot + lane_v,
+                             ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, bs),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long *src[8] = {lane < 13 ? bslot + lane : nullptr, nullptr, nullptr, nullptr,
-                                            nullptr, nullptr, nullptr, nullptr};
-        unsigned long long g[8];
-        res_poll(pc, src, g, tag, lane);
+        const unsigned long long g = res_poll1(pc, lane < 13 ? bslot + lane_v : nullptr, tag, lane);
         // a time-out ends the pair in this workgroup (bounded time; the host reports the tracking as failed)
-        if (lane < 13) sG[lane] = (lane == 12 && pc.dead) ? 0.0f : __builtin_bit_cast(float, (unsigned)(g[0] & 0xffffffffu));
+        if (lane < 13) sG[lane] = (lane == 12 && pc.dead) ? 0.0f : __builtin_bit_cast(float, (unsigned)(g & 0xffffffffu));
         RES_MARK(4)  // worker (wave 0): gather store + waiting for the broadcast
       }
       __syncthreads();
@@ -441,34 +575,48 @@ __global__ __launch_bounds__(64 * kResWaves, 4) void k_level_resident(EngineDev 
 size_t resident_mail_bytes(int parts, int slots) {
   return sizeof(unsigned long long) * (size_t)slots * ((size_t)2 * parts * kResSlot + 2 * 16);
 }
-int resident_points_per_workgroup(void) { return kResQ; }
+int resident_points_per_workgroup(int np) { return kResWaves * np; }
 // workgroups of this kernel that one CU holds at once (0: the kernel cannot run)
-int resident_blocks_per_cu(void) {
-  static const int n = [] {
-    int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void *>(&k_level_resident),
-                                                     64 * kResWaves, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      v = 0;
-    }
-    return v;
-  }();
-  return n;
+int resident_blocks_per_cu(int np) {
+  static const int n[2] = {
+      [] {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void *>(&k_level_resident<16>),
+                                                         kResThreads, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          v = 0;
+        }
+        return v;
+      }(),
+      [] {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void *>(&k_level_resident<32>),
+                                                         kResThreads, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          v = 0;
+        }
+        return v;
+      }()};
+  return n[np == 32 ? 1 : 0];
 }
-hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int parts, int slots, int nblk,
+hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int np, int parts, int slots, int nblk,
                                  unsigned tag0, unsigned long long limit, unsigned long long *mail, int *err,
-                                 hipStream_t s) {
+                                 int dbg_mute, hipStream_t s) {
   ResArgs a;
   a.nblk = nblk;
   a.lc = lc;
   a.level = level;
   a.parts = parts;
   a.slots = slots;
+  a.dbg_mute = dbg_mute;
   a.tag0 = tag0;
   a.limit = limit;
   a.mail = mail;
   a.err = err;
-  hipLaunchKernelGGL(k_level_resident, dim3((parts + 1) * slots), dim3(64 * kResWaves), 0, s, e, a);
+  if (np == 32)
+    hipLaunchKernelGGL(k_level_resident<32>, dim3((parts + 1) * slots), dim3(kResThreads), 0, s, e, a);
+  else
+    hipLaunchKernelGGL(k_level_resident<16>, dim3((parts + 1) * slots), dim3(kResThreads), 0, s, e, a);
   return hipGetLastError();
 }
 

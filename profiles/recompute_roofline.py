@@ -35,7 +35,7 @@ def short(name):
     return None
 
 
-def from_trace(path, points, reduce_to=None, pairs=None):
+def from_trace(path, points, reduce_to=None, pairs=None, res_pairs=32, maxiter=10):
     rows = []
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
@@ -49,7 +49,7 @@ def from_trace(path, points, reduce_to=None, pairs=None):
         pairs = 16  # bench.py's default: --batch 32 over --streams 2 engines
     if reduce_to:
         # keep the headline's dispatches (the secondary records launch thousands of small ones) and the markers
-        rows = [r for r in rows if r[2] == "k_stream_read" or r[3] == pairs]
+        rows = [r for r in rows if r[2] in ("k_stream_read", "k_level_res") or r[3] == pairs]
         with open(reduce_to, "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size_Y"])
@@ -69,6 +69,7 @@ def from_trace(path, points, reduce_to=None, pairs=None):
     if not it_solo:
         print("no un-overlapped k_iter8 dispatch in this trace")
         return 1
+    frac = 0.0
 
     def report(tag, lst):
         byts = sum(16.0 * 64 * points * gy for _, gy in lst)
@@ -88,12 +89,33 @@ def from_trace(path, points, reduce_to=None, pairs=None):
             frac = report("k_iter8, solo leg (marker)", leg)
     else:
         print("(no k_stream_read marker in this trace: the figure is that of the dispatches running alone)")
-    for k in ("k_ref8", "k_level_res"):
+    for k in ("k_ref8",):
         lst = [(e - s, gy) for a, (s, e, kk, gy, _) in zip(alone, rows) if a and kk == k]
         if lst:
             ns = sum(d for d, _ in lst)
             print(f"{k + ', running alone':28s} {len(lst):6d} launches, mean {ns / len(lst) / 1e3:8.2f} us")
-    print(f"roofline.frac = {frac:.4f}")
+    # resident-iteration headline (r03): the k_level_resident dispatches between the FIRST group of markers (the
+    # streaming-read yardstick before the run) and the next one (the marker of the streaming leg behind the timed steps)
+    groups, prev = [], None
+    for i, r in enumerate(rows):
+        if r[2] == "k_stream_read":
+            if prev is None or i != prev + 1:
+                groups.append([i, i])
+            groups[-1][1] = i
+            prev = i
+    res = [(e - s) for (s, e, k, gy, _) in (rows[groups[0][1]:groups[1][0]] if len(groups) >= 2 else rows)
+           if k == "k_level_res"]
+    if res:
+        mean = sum(res) / len(res)
+        byts = 16.0 * 64 * points * res_pairs * maxiter
+        rate = byts / (mean * 1e-9)
+        print(f"{'k_level_resident, headline':28s} {len(res):6d} launches, mean {mean / 1e3:8.2f} us, {byts / 1e9:.2f} GB "
+              f"algorithmic per launch ({res_pairs} pairs x {maxiter} iterations): {rate / 1e9:8.1f} GB/s equivalent = "
+              f"{rate / PEAK:.4f} of 8 TB/s")
+        print(f"roofline.frac = {rate / PEAK:.4f}   (headline kernel k_level_resident)")
+        print(f"roofline.streaming_kernel.frac = {frac:.4f}   (k_iter8, solo leg)")
+    else:
+        print(f"roofline.frac = {frac:.4f}")
     return 0
 
 
@@ -125,12 +147,14 @@ def main():
     ap.add_argument("--pairs", type=int, default=None,
                     help="frame pairs per launch = the dispatch's grid size in y (trace input: default 16, bench.py's "
                          "--batch 32 over two engines; --stats input: default 32, one engine)")
+    ap.add_argument("--res-pairs", type=int, default=32, help="frame pairs per k_level_resident launch (bench default 32)")
+    ap.add_argument("--maxiter", type=int, default=10)
     ap.add_argument("--reduce", default=None, help="trace input: also write the reduced trace here")
     a = ap.parse_args()
     with open(a.csv, newline="") as f:
         header = f.readline()
     if "Start_Timestamp" in header:
-        return from_trace(a.csv, a.points, a.reduce, a.pairs)
+        return from_trace(a.csv, a.points, a.reduce, a.pairs, a.res_pairs, a.maxiter)
     return from_stats(a.csv, a.points, a.pairs or 32)
 
 

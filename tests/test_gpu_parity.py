@@ -367,6 +367,28 @@ def test_team_launches_on_many_streams_are_admitted_without_starving_each_other(
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("npw", [32, 16])
+def test_transposing_wave_reduction_of_the_resident_kernel(npw):
+    """k_level_resident sums the per-lane values of a wave (A = Gx r and B = Gy r of its 32 or 16 patches) over the 64 lanes
+    with a transposing reduction -- bank-masked DPP adds, v_permlane16/32_swap, quad permutes -- that leaves lane l with the
+    complete sum of ONE value. The reduction alone, on integers (exact in float32): every lane must hold exactly the sum
+    of the value the kernel believes it holds (tr_patch_of_lane / tr_kind_of_lane), and the lanes must cover all values
+    (with 16 patches per wave every value sits in two lanes)."""
+    from invcompcamtrack_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    vals = rng.integers(-500, 500, (64, 64)).astype(np.float32)
+    out = np.zeros(64, np.float32)
+    pl, kl = np.zeros(64, np.int32), np.zeros(64, np.int32)
+    _lib.check(L.ictr_debug_transpose_reduce(_lib.fp(vals), _lib.fp(out), pl.ctypes.data_as(_lib.IP),
+                                             kl.ctypes.data_as(_lib.IP), npw))
+    idx = 2 * pl + kl
+    assert sorted(set(idx.tolist())) == list(range(2 * npw)), "the lanes must hold every value"
+    assert np.bincount(idx, minlength=2 * npw).tolist() == [64 // (2 * npw)] * (2 * npw)
+    want = vals.sum(axis=0)[idx]
+    assert np.array_equal(out, want), (np.flatnonzero(out != want), out[:8], want[:8])
+
+
 @pytest.mark.parametrize("B,ratio,maxiter", [(1, 0.0, 6), (3, 0.0, 6), (5, 0.01, 10), (2, 0.0, 1)])
 def test_resident_iterations_equal_per_iteration_launches(oracle, B, ratio, maxiter):
     """k_level_resident (all iterations of a level in ONE launch: templates resident in registers / LDS, a mailbox
