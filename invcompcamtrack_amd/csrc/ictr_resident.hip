@@ -49,6 +49,10 @@ struct ResArgs {
   int parts, slots;          // worker workgroups per frame pair; pairs in flight (grid = slots * (parts + 1))
   int nblk;                  // workgroups per problem of the level's setup launch (their H partials: e.partH)
   int dbg_mute;              // debug (variant bit 25): worker `dbg_mute - 1` never posts its sums (time-out test); 0 = off
+  int prof_slot;             // ICTR_RES_PROF builds: the slot whose worker 0 / solver report their cycle counters
+  int stagger;               // slot s starts s * stagger ticks (100 MHz) late: the pairs in flight on a CU leave lockstep
+  int abl;                   // timing ablations (ICTR_RES_ABL, wrong results): 1 every window = the plane's first, 2 no window loads in the loop
+  int prio_mode;             // wave priorities (s_setprio): 0 none; 1 by slot; 2 by slot, rotating with the slot's pair count
   unsigned tag0;             // launch epoch << 12
   unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
   unsigned long long *mail;  // per slot: gather box [2][parts][kResSlot], then broadcast box [2][16]
@@ -260,12 +264,26 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
     tp_[k] += t1_ - t0_;                   \
     t0_ = t1_;                             \
   }
+// time line (tools/restrace.py): 100 MHz wall-clock stamps of wave 0 of the workers that share CU `blockIdx % 256 == 0`
+// (rows 0..7: one per slot) and of every slot's solver workgroup (rows 8..15), four stamps per iteration
+constexpr int kTrIters = 128;
+__device__ unsigned long long g_res_trace[16][kTrIters][4];
+#define RES_STAMP(row, it, k) \
+  if ((row) >= 0 && (it) < kTrIters && tid == 0) g_res_trace[row][it][k] = wall_clock64();
 #else
 #define RES_MARK(k)
+#define RES_STAMP(row, it, k)
 #endif
 struct ResWin {
   f32x2_a4 ab, cd;  // (x-1,y),(x,y) and (x-1,y-1),(x,y-1)
 };
+
+__device__ __forceinline__ void res_setprio(int p) {  // wave-uniform p in 0..3 (the instruction takes an immediate)
+  if (p == 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
 
 // Register budget: 128 per wave = four 4-wave workgroups per CU (launch bounds), 64 of them Gx / Gy of the wave's patches.
 template <int NP>
@@ -294,10 +312,17 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
   pc.dead = 0;
   unsigned seq = 0;
 #ifdef ICTR_RES_PROF
+  const int tr_row = part == parts ? (slot < 8 ? 8 + slot : -1) : ((part == 0 && slot < 8) ? slot : -1);
+  int tr_it = 0;
   unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter(), t1_ = 0;
 #endif
 
+  if (a.stagger > 0 && slot > 0) {
+    const unsigned long long t0s = wall_clock64(), dts = (unsigned long long)slot * (unsigned)a.stagger;
+    while (wall_clock64() - t0s < dts) __builtin_amdgcn_s_sleep(8);
+  }
   if (part == parts) {
+    if (a.prio_mode) __builtin_amdgcn_s_setprio(3);
     // ================================================================ the pair's solver workgroup
     SolveOpts sopt = solve_opts(e);
     sopt.robust = 0;
@@ -349,6 +374,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
         // lane (k, rr) = 8 k + rr (k < 6) reads value k of the workers ((8 wave + u) 8 + rr), u = 0..7: eight granule
         // loads in flight per lane, 256 workers per round trip; sums in a fixed order: u, rounds, rr, waves
         RES_MARK(0)  // solver: loop overhead / barrier behind the previous broadcast
+        RES_STAMP(tr_row, tr_it, 0)
         const int k = lane >> 3, rr = lane & 7;
         double accd = 0.0;
         for (int r0 = 0; r0 < parts; r0 += 64 * kResWaves) {
@@ -366,9 +392,11 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
         }
         const double tot = res_sum8(accd);
         RES_MARK(1)  // solver: waiting for / summing the workers' granules
+        RES_STAMP(tr_row, tr_it, 1)
         if (rr == 0 && k < 6) sRed[wave][k] = tot;
         __syncthreads();
         RES_MARK(2)  // solver: barrier
+        RES_STAMP(tr_row, tr_it, 2)
         if (wave == 0) {
           double bsum = 0.0;
           if (lane < 6)
@@ -390,7 +418,11 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (lane == 0) sG[12] = __builtin_bit_cast(float, act);
           RES_MARK(3)  // solver: solve + broadcast
+          RES_STAMP(tr_row, tr_it, 3)
         }
+#ifdef ICTR_RES_PROF
+        tr_it += 1;
+#endif
         __syncthreads();
         active = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sG[12]));
       }
@@ -402,7 +434,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
       __syncthreads();
     }
 #ifdef ICTR_RES_PROF
-    if (slot == 0 && tid == 0)
+    if (slot == a.prof_slot && tid == 0)
       for (int k = 0; k < 8; ++k) e.partH[8 + k] = (float)tp_[k];
 #endif
     return;
@@ -417,7 +449,8 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
   float *const tw = sT[wave] + lane;
   const int my_patch = tr_patch_of_lane<NP>(lane);  // the (patch, A|B) whose complete sum this lane holds after stage 2
   const int my_kind = tr_kind_of_lane(lane);
-  for (int b = slot; b < e.B; b += a.slots) {
+  for (int b = slot, round = 0; b < e.B; b += a.slots, ++round) {
+    if (a.prio_mode) res_setprio((a.prio_mode == 2 ? slot + round : slot) & 3);
     const ProbState &gst = e.st[b];
     const int npts = gst.npts;
     int active = ((0 < e.maxiter) & (1.0f > e.ratio)) ? 1 : 0;  // as the solver workgroup evaluates it (odometer.cpp:341-346)
@@ -474,6 +507,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
 
     while (active) {  // uniform over the pair's workgroups: every one of them follows the same broadcast
       RES_MARK(0)  // worker: barrier behind the broadcast
+      RES_STAMP(tr_row, tr_it, 0)
       // ---- stage 1 (pose.cpp:384-391, odometer.cpp:369-377): lane l < 32 <-> point i0 + l
       int base_v;
       float vis_f;
@@ -501,7 +535,8 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
       // transposing reduction: a patch's (A, B) pair merges on lane bit 2, then a binary counter of pending registers
       ResWin W[kResD];
       auto issue = [&](int j) {
-        const int soff = rlane(base_v, j);
+        if (a.abl == 2 && j >= kResD) return;
+        const int soff = a.abl == 1 ? 0 : rlane(base_v, j);
         W[j % kResD].cd = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_cd, soff, 0));
         W[j % kResD].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_ab, soff, 0));
       };
@@ -527,6 +562,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
       });
       const float F = acc.F;
       RES_MARK(2)  // worker: stage 2
+      RES_STAMP(tr_row, tr_it, 1)
       // ---- lane = (patch, A|B): its point's visibility and coefficients, then the six sums over the wave
       {
         const float val = F * lane_gather(vis_f, my_patch);  // 0 out of the new view (ind_new) and beyond the wave's points
@@ -540,6 +576,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
       }
       __syncthreads();
       RES_MARK(3)  // worker: wave reduction + barrier
+      RES_STAMP(tr_row, tr_it, 2)
       // ---- gather: the workgroup's six sums -> the pair's mailbox; then the broadcast
       seq += 1;
       const unsigned tag = a.tag0 + seq;
@@ -558,7 +595,11 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
         // a time-out ends the pair in this workgroup (bounded time; the host reports the tracking as failed)
         if (lane < 13) sG[lane] = (lane == 12 && pc.dead) ? 0.0f : __builtin_bit_cast(float, (unsigned)(g & 0xffffffffu));
         RES_MARK(4)  // worker (wave 0): gather store + waiting for the broadcast
+        RES_STAMP(tr_row, tr_it, 3)
       }
+#ifdef ICTR_RES_PROF
+      tr_it += 1;
+#endif
       __syncthreads();
       active = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sG[12]));
     }
@@ -566,12 +607,22 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
     __syncthreads();  // sG and the records are rewritten for the next pair
   }
 #ifdef ICTR_RES_PROF
-  if (blockIdx.x == 0 && tid == 0)
+  if (slot == a.prof_slot && part == 0 && tid == 0)
     for (int k = 0; k < 8; ++k) e.partH[k] = (float)tp_[k];
 #endif
 }
 
 // ---------------------------------------------------------------- host side
+#ifdef ICTR_RES_PROF
+extern "C" int ictr_prof_res_trace(unsigned long long *out, int clear) {  // out[16][128][4]
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_trace), sizeof(g_res_trace)) != hipSuccess) return 1;
+  if (clear) {
+    static unsigned long long z[16][kTrIters][4];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_res_trace), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 size_t resident_mail_bytes(int parts, int slots) {
   return sizeof(unsigned long long) * (size_t)slots * ((size_t)2 * parts * kResSlot + 2 * 16);
 }
@@ -601,8 +652,19 @@ int resident_blocks_per_cu(int np) {
 }
 hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int np, int parts, int slots, int nblk,
                                  unsigned tag0, unsigned long long limit, unsigned long long *mail, int *err,
-                                 int dbg_mute, hipStream_t s) {
+                                 int dbg_mute, int prio_mode, hipStream_t s) {
   ResArgs a;
+  a.prio_mode = prio_mode;
+  {
+    const char *ps = getenv("ICTR_RESIDENT_STAGGER");
+    a.stagger = ps ? atoi(ps) : 0;
+    ps = getenv("ICTR_RES_ABL");
+    a.abl = ps ? atoi(ps) : 0;
+  }
+  {
+    const char *ps = getenv("ICTR_RES_PROF_SLOT");
+    a.prof_slot = ps ? atoi(ps) : 0;
+  }
   a.nblk = nblk;
   a.lc = lc;
   a.level = level;

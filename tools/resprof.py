@@ -17,7 +17,7 @@ for r in range(3):
     e.SetPoseAll(np.tile(sc["p_a"], (B, 1)), pa, pb)
     e.track_async()
     e.poses()
-c = np.concatenate([e.read_buffer(0, 9, 8), e.read_buffer(1, 9, 8)])
+c = e.read_buffer(0, 9, 16)
 print(e.path_name())
 names_w = ["barrier", "stage1", "stage2", "reduce+barrier", "gather+wait broadcast", "pair prologue", "-", "-"]
 names_s = ["loop/barrier", "wait+sum granules", "barrier", "solve+broadcast", "-", "-", "-", "-"]
