@@ -44,12 +44,12 @@ void launch_iter_finish(const EngineDev &, int, int, int, hipStream_t);
 bool defer_h(const EngineDev &, int);
 hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t,
                          const T1Team *);
-hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, int, int, unsigned,
+hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, int, int, int, unsigned,
                                  unsigned long long, unsigned long long *, int *, int, int, hipStream_t);
 hipError_t launch_debug_transpose_reduce(const float *, float *, int *, int *, int, hipStream_t);
 size_t resident_mail_bytes(int, int);
 int resident_points_per_workgroup(int);
-int resident_blocks_per_cu(int);
+int resident_blocks_per_cu(int, int);
 int track1_team_q(int, int);
 int track1_team_size(int, int);
 size_t track1_team_mail_bytes(int, int);
@@ -1441,7 +1441,11 @@ static int team_prepare(ictr_batch *b, T1Team *tm) {
 // camera, grid shapes -- all of it goes into the key). Variant bit 15 (32768) keeps the plain launches (A/B).
 struct ResPlan {  // resident-iteration form (below): worker workgroups per frame pair, pairs in flight; 0 = not this form
   int parts = 0, slots = 0;
-  int np = 32;  // patches per wave of the kernel instantiation (32: four 1080p pairs in flight; 16: one or two pairs)
+  int np = 32;    // patches per wave of the kernel instantiation (32: four 1080p pairs in flight; 16: one or two pairs)
+  int fused = 0;  // variant bit 26 (67108864): the level's setup inside the launch (no k_ref8 launch, no template round trip
+                  // through HBM). Measured slower -- 4.39 against 4.04 ms per 32 pairs: the setup is ~3500 instructions per
+                  // wave and runs on ONE wave per SIMD there (80 us per pair and level) instead of on every wave slot of the
+                  // chip in k_ref8 (48 us per pair equivalent) -- so it stays an A/B form (profiles/r03_notes.md)
 };
 static ResPlan resident_plan(const ictr_batch *b);
 static bool use_graph(const ictr_batch *b) {
@@ -1498,9 +1502,10 @@ static ResPlan resident_plan(const ictr_batch *b) {
   static const int force_np = env_int("ICTR_RESIDENT_NP", 0);             // experiments: 16 or 32
   // sixteen patches per wave (twice the workgroups, half the patch loop) when ALL pairs of the batch are then in flight
   // at once; thirty-two (the most templates a CU can hold: four 1080p pairs in flight) otherwise
+  p.fused = (v & (1 << 26)) ? 1 : 0;
   for (int np : {16, 32}) {
     if (force_np && np != force_np) continue;
-    const int bpc = resident_blocks_per_cu(np);
+    const int bpc = resident_blocks_per_cu(np, p.fused);
     if (bpc < 1) continue;
     const int q = resident_points_per_workgroup(np);
     const int parts = (b->maxpts + q - 1) / q;
@@ -1552,12 +1557,12 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
     return t ? std::max(0.001, atof(t)) : 5.0;
   }();
   // every workgroup of the launch must be resident: it starts when its slots are free of team / resident launches
-  const int bpc = std::max(1, std::min(4, resident_blocks_per_cu(p.np)));
+  const int bpc = std::max(1, std::min(4, resident_blocks_per_cu(p.np, p.fused)));
   const int weight = p.slots * (p.parts + 1) * (4 / bpc);
   const int mute = (engine_variant(b) & (1 << 25)) ? 1 : 0;  // debug: worker 0 never posts its sums (time-out test)
   static const int prio_mode = env_int("ICTR_RESIDENT_PRIO", 2);  // rotating wave priorities: 4.29 -> 4.03 ms per 32 pairs (r03 notes)
   return team_launch(weight, s, [&]() -> int {
-    HIPCHK(launch_level_resident(e, lc, level, p.np, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
+    HIPCHK(launch_level_resident(e, lc, level, p.np, p.fused, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
                                  (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, mute, prio_mode, s));
     return ICTR_OK;
   });
@@ -1572,7 +1577,7 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
       const LevelCam lc = level_cam(b->cam, sl);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
-      launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 24), b->cpw, b->gridx8, s);
+      if (!rp.fused) launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 24), b->cpw, b->gridx8, s);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
       if (int rc = launch_resident(b, e, lc, sl, rp, s)) return rc;
       if (events) {

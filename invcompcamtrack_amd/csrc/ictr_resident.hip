@@ -51,15 +51,17 @@ struct ResArgs {
   int dbg_mute;              // debug (variant bit 25): worker `dbg_mute - 1` never posts its sums (time-out test); 0 = off
   int prof_slot;             // ICTR_RES_PROF builds: the slot whose worker 0 / solver report their cycle counters
   int stagger;               // slot s starts s * stagger ticks (100 MHz) late: the pairs in flight on a CU leave lockstep
-  int abl;                   // timing ablations (ICTR_RES_ABL, wrong results): 1 every window = the plane's first, 2 no window loads in the loop
   int prio_mode;             // wave priorities (s_setprio): 0 none; 1 by slot; 2 by slot, rotating with the slot's pair count
   unsigned tag0;             // launch epoch << 12
   unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
-  unsigned long long *mail;  // per slot: gather box [2][parts][kResSlot], then broadcast box [2][16]
+  unsigned long long *mail;  // per slot: gather box [2][parts][kResSlot], broadcast box [2][16], H box [parts][kResHSlot]
   int *err;                  // sticky time-out flag (pinned host memory as the device sees it)
 };
 
-__device__ __forceinline__ size_t res_slot_granules(int parts) { return (size_t)2 * parts * kResSlot + 2 * 16; }
+constexpr int kResHSlot = 24;               // granules per worker workgroup in the H box (21 used; fused setup only)
+__host__ __device__ __forceinline__ size_t res_slot_granules(int parts) {
+  return (size_t)2 * parts * kResSlot + 2 * 16 + (size_t)parts * kResHSlot;
+}
 
 struct ResPoll {
   unsigned long long limit;
@@ -286,12 +288,43 @@ __device__ __forceinline__ void res_setprio(int p) {  // wave-uniform p in 0..3 
 }
 
 // Register budget: 128 per wave = four 4-wave workgroups per CU (launch bounds), 64 of them Gx / Gy of the wave's patches.
+// fused setup: after patch j is consumed, the windows of the patches up to res_upto(j) have been requested (j = -1: before
+// the first). The depth shrinks as the template registers fill up (two registers per finished patch, twelve per window)
 template <int NP>
+constexpr int res_upto(int j) {
+  if (j < 0) return (NP < 7 ? NP : 7) - 1;
+  int d = (90 - 2 * j) / 12;
+  d = d > 7 ? 7 : (d < 2 ? 2 : d);
+  const int u = j + d;
+  return u > NP - 1 ? NP - 1 : u;
+}
+template <int FROM, int TO, class Fn>
+__device__ __forceinline__ void res_issue_range(Fn &&fn) {  // fn(k) for k = FROM .. TO (compile-time bounds)
+  if constexpr (FROM <= TO) {
+    fn(FROM);
+    res_issue_range<FROM + 1, TO>(fn);
+  }
+}
+// inverse of tr_patch_of_lane / tr_kind_of_lane: the (primary) lane that holds sum `kind` of patch p
+template <int NP>
+__device__ __forceinline__ int tr_lane_of(int p, int kind) {
+  return ((p >> 3) & 1) | ((NP == 32 ? ((p >> 4) & 1) : 0) << 1) | (kind << 2) | ((p & 1) << 3) | (((p >> 1) & 1) << 4) |
+         (((p >> 2) & 1) << 5);
+}
+
+// FUSED: the level's setup (steps 4-6: odometer.cpp:268-334, 428-472) happens in the pair's prologue -- every wave
+// gathers and blends the reference patches of its own points straight into the registers / LDS they stay in, sums
+// S = (sum Gx^2, sum Gx Gy, sum Gy^2) per patch and posts the workgroup's part of H = sum J^T S J to the pair's solver
+// workgroup; T / Gx / Gy / coefficients are still written through to the batch's buffers (the state that later levels
+// and later trackings fall back to for points out of view, odometer.cpp:304; what read_buffer shows), but nothing is
+// read back from them except such stale patches. No setup launch, no k_level_tail.
+template <int NP, bool FUSED>
 __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, ResArgs a) {
   constexpr int kResPPW = NP, kResQ = kResWaves * NP;
   __shared__ __attribute__((aligned(16))) float4 sRecW[kResWaves][kResPPW];  // per point: bilinear weights [w1 w0 w3 w2]
   __shared__ float sT[kResWaves][kResPPW * 64];  // T of the wave's patches (lane = pixel)
   __shared__ float sPart[kResWaves][8];
+  __shared__ float sPartH[kResWaves][32];  // FUSED: the waves' parts of H (21 used)
   __shared__ double sRed[kResWaves][8];
   __shared__ float sG[16];   // cpos_G of the current iteration, [12] = loop flag (bits)
   __shared__ ProbState sSt;  // solver workgroup: the problem's state between the solver's turns
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
   const int M = e.M;
   unsigned long long *gbox = a.mail + (size_t)slot * res_slot_granules(parts);
   unsigned long long *bbox = gbox + (size_t)2 * parts * kResSlot;
+  unsigned long long *hbox = bbox + 2 * 16;
   ResPoll pc;
   pc.limit = a.limit;
   pc.err = a.err;
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
     sopt.robust = 0;
     __shared__ double sRedH[kResThreads / 32][32];
     __shared__ float sH[32];
-    for (int b = slot; b < e.B; b += a.slots) {
+    for (int b = slot, round = 0; b < e.B; b += a.slots, ++round) {
       const ProbState &gst = e.st[b];
       // loop condition of odometer.cpp:341-346 at the start of a level: normdp / normdp_init = 1 (every workgroup of the
       // pair evaluates it for itself; maxiter >= 1 is the host's condition for this form)
@@ -338,16 +372,34 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
         unsigned *dst = reinterpret_cast<unsigned *>(&sSt);
         for (int i = tid; i < (int)(sizeof(ProbState) / 4); i += kResThreads) dst[i] = src[i];
       }
-      // ---- what k_level_tail does in the other launch forms: fixed-order f64 sum of the setup launch's H partials
-      // (8 slices x 32 components, then the slices in order), full-pivot LU once per level, loop state reset --
-      // while the pair's workers load their templates
+      // ---- what k_level_tail does in the other launch forms: fixed-order f64 sum of the H partials (8 slices x 32
+      // components, then the slices in order), full-pivot LU once per level, loop state reset. Unfused: the setup
+      // launch's partials (e.partH), while the pair's workers load their templates; FUSED: the workers' own partials out
+      // of the pair's H box (granules tagged with the slot's pair count), while they run their first stage 2
       {
         const int j = tid & 31, sl = tid >> 5;
         double sacc = 0.0;
-        const float *ph = e.partH + (size_t)b * a.nblk * kPartHStride + j;
-        if (j < kHUnique) {
+        if constexpr (FUSED) {
+          const unsigned tagh = a.tag0 + (unsigned)round + 1u;
+          for (int r0 = 0; r0 < parts; r0 += 8 * (kResThreads / 32)) {
+            const unsigned long long *src[8];
+            unsigned long long g[8];
+#define RES_HSRC(u)                                                                        \
+  {                                                                                        \
+    const int r = r0 + u * (kResThreads / 32) + sl;                                        \
+    src[u] = (j < kHUnique && r < parts) ? hbox + (size_t)r * kResHSlot + j : nullptr;     \
+  }
+            RES_EACH8(RES_HSRC)
+            res_poll(pc, src, g, tagh, lane);
+#define RES_HACC(u) sacc += (double)__builtin_bit_cast(float, (unsigned)(g[u] & 0xffffffffu));
+            RES_EACH8(RES_HACC)
+          }
+        } else {
+          const float *ph = e.partH + (size_t)b * a.nblk * kPartHStride + j;
+          if (j < kHUnique) {
 #pragma unroll 8
-          for (int k = sl; k < a.nblk; k += kResThreads / 32) sacc += (double)ph[(size_t)k * kPartHStride];
+            for (int k = sl; k < a.nblk; k += kResThreads / 32) sacc += (double)ph[(size_t)k * kPartHStride];
+          }
         }
         sRedH[sl][j] = sacc;
       }
@@ -467,43 +519,217 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
     }
     const __amdgpu_buffer_rsrc_t rcur =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cur_plane), 0, 0x7fffffff, 0x00020000);
-    // ---- templates of this wave's patches (written by the level's setup launch; stale ones included): Gx, Gy into
-    // registers, T into LDS
-    float Gx[kResPPW], Gy[kResPPW];
-    {
-      const float *gT = e.T + ((size_t)b * M + i0) * 64 + lane;
-      const float *gGx = e.Gx + ((size_t)b * M + i0) * 64 + lane;
-      const float *gGy = e.Gy + ((size_t)b * M + i0) * 64 + lane;
+    f32x2_t Gxy[kResPPW];  // {Gx, Gy} of the lane's pixel, patch by patch: one register pair, one packed multiply by r
+    const float *gT = e.T + ((size_t)b * M + i0) * 64 + lane;
+    const float *gGx = e.Gx + ((size_t)b * M + i0) * 64 + lane;
+    const float *gGy = e.Gy + ((size_t)b * M + i0) * 64 + lane;
+    const bool pv = lane < cnt;
+    float c6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (FUSED) {
+      // ---- setup, stage 1 (lane l < NP <-> point i0 + l): visibility in the reference view (odometer.cpp:273-282),
+      // steepest-descent coefficients (:313-326; a point out of view keeps its stale line, :304), bilinear weights and
+      // window base of the reference patch (utilities.cpp:66-77)
+      const PlaneSet *plp = e.planes + (b * e.nlev + a.level);
+      auto uniform_plane = [](const float *q) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff,
+                                                 0x00020000);
+      };
+      const __amdgpu_buffer_rsrc_t rref = uniform_plane(plp->ref), rdx = uniform_plane(plp->dx), rdy = uniform_plane(plp->dy);
+      const float *pt2 = e.pt2d + ((size_t)b * e.nlev + a.level) * 2 * M;
+      const float *p3r = e.pt3d_ref + (size_t)b * 3 * M;
+      const int ip = i0 + lane;
+      float mx = 0.0f, my = 0.0f;
+      if (pv) {
+        mx = pt2[ip];
+        my = pt2[ip + M];
+      }
+      const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+      float cx[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, cy[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (pv) {
+        float4 *c4 = reinterpret_cast<float4 *>(e.coef + ((size_t)b * M + ip) * kCoefStride);
+        if (vis) {
+          sd_coefs(p3r[ip], p3r[ip + M], p3r[ip + 2 * M], lc.fx, lc.fy, cx, cy);
+          c4[0] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+          c4[1] = make_float4(cx[4], cx[5], cy[0], cy[1]);
+          c4[2] = make_float4(cy[2], cy[3], cy[4], cy[5]);
+        } else {
+          const float4 a0 = c4[0], a1 = c4[1], a2 = c4[2];
+          cx[0] = a0.x; cx[1] = a0.y; cx[2] = a0.z; cx[3] = a0.w; cx[4] = a1.x; cx[5] = a1.y;
+          cy[0] = a1.z; cy[1] = a1.w; cy[2] = a2.x; cy[3] = a2.y; cy[4] = a2.z; cy[5] = a2.w;
+        }
+      }
+      const unsigned vmask = (unsigned)__builtin_amdgcn_ballot_w64(vis);          // points are lanes 0 .. NP-1 <= 31
+      const unsigned smask = (unsigned)__builtin_amdgcn_ballot_w64(pv && !vis);   // stale patches stay in force
+      int base_r;
+      {
+        const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);  // (1,1): a harmless in-plane window
+        base_r = ((tp.row0 - 1) * sw + tp.col0 - 1) * 4;
+        if (lane < kResPPW) recs[lane] = make_float4(tp.w1, tp.w0, tp.w3, tp.w2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- setup, stage 2 (utilities.cpp:115-189; lane = pixel): the three planes' windows. What bounds this phase
+      // is the number of windows a wave has in flight (first-touch latency of the reference planes), and early in the
+      // loop most template registers are still free: seven patches in flight at the start, two at the end (res_depth).
+      // Blends in the reference's operand order, products rounded one by one (bit-identical to k_ref8 / the CPU path)
+      struct RefWin {
+        f32x2_a4 ab[3], cd[3];
+      };
+      RefWin RW[8];
+      auto issue_ref = [&](int j) {
+#if defined(ICTR_RES_ABL) && ICTR_RES_ABL == 4  // timing ablation: every reference window = the plane's first
+        const int soff = 0;
+#else
+        const int soff = rlane(base_r, j);
+#endif
+        RefWin &w = RW[j & 7];
+        w.cd[0] = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rref, (int)off_cd, soff, 0));
+        w.ab[0] = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rref, (int)off_ab, soff, 0));
+        w.cd[1] = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rdx, (int)off_cd, soff, 0));
+        w.ab[1] = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rdx, (int)off_ab, soff, 0));
+        w.cd[2] = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rdy, (int)off_cd, soff, 0));
+        w.ab[2] = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rdy, (int)off_ab, soff, 0));
+      };
+      tr_for_each_patch<res_upto<NP>(-1) + 1, 0>([&](auto jc) { issue_ref(decltype(jc)::value); });
+      tr_for_each_patch<NP, 0>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float4 wv = recs[j];
+        const RefWin w = RW[j & 7];
+        float v3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f32x2_t pab = f32x2_t{wv.x, wv.y} * f32x2_t{w.ab[k].x, w.ab[k].y};
+          const f32x2_t pcd = f32x2_t{wv.z, wv.w} * f32x2_t{w.cd[k].x, w.cd[k].y};
+          v3[k] = ((pab.y + pab.x) + pcd.y) + pcd.x;
+        }
+        asm volatile("" ::: "memory");  // (the next windows are requested only now: their registers are this patch's)
+        res_issue_range<res_upto<NP>(j - 1) + 1, res_upto<NP>(j)>(issue_ref);
+        const bool vj = (vmask >> j) & 1u;  // wave-uniform
+        const float t = vj ? v3[0] : 0.0f;
+        Gxy[j] = f32x2_t{vj ? v3[1] : 0.0f, vj ? v3[2] : 0.0f};
+        tw[j * 64] = t;
+#if defined(ICTR_RES_ABL) && ICTR_RES_ABL == 3  // timing ablation: no write-through
+        if (false) {
+#else
+        if (vj) {  // written through: the state a point falls back to when it leaves the reference view
+#endif
+          __builtin_nontemporal_store(t, const_cast<float *>(gT) + j * 64);
+          __builtin_nontemporal_store(Gxy[j].x, const_cast<float *>(gGx) + j * 64);
+          __builtin_nontemporal_store(Gxy[j].y, const_cast<float *>(gGy) + j * 64);
+        }
+      });
+      if (smask != 0u) {  // rare: points out of the reference view at this level keep their stale patches
+        tr_for_each_patch<NP, 0>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if ((smask >> j) & 1u) {
+            const float t = __builtin_nontemporal_load(gT + j * 64);
+            Gxy[j].x = __builtin_nontemporal_load(gGx + j * 64);
+            Gxy[j].y = __builtin_nontemporal_load(gGy + j * 64);
+            tw[j * 64] = t;
+          }
+        });
+      }
+      // ---- S = (sum Gx^2, sum Gx Gy, sum Gy^2) of every patch by the transposing reduction: lane (patch, kind) of accS
+      // holds Sxx | Syy, lane (pair, kind) of accX the Sxy of patch pair | pair + 16; then lane = point again
+      TrAcc<NP> accS;
+      tr_for_each_patch<NP, 0>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const f32x2_t q = Gxy[j] * Gxy[j];
+        accS.template push<j>(q.x, q.y, lane);
+      });
+      TrAcc<16> accX;
+      tr_for_each_patch<16, 0>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (NP == 32)
+          accX.template push<j>(Gxy[j].x * Gxy[j].y, Gxy[j + 16].x * Gxy[j + 16].y, lane);
+        else
+          accX.template push<j>(Gxy[j].x * Gxy[j].y, 0.0f, lane);
+      });
+      {
+        const int pp = lane & (NP - 1);
+        const float sxx = lane_gather(accS.F, tr_lane_of<NP>(pp, 0)), syy = lane_gather(accS.F, tr_lane_of<NP>(pp, 1));
+        const float sxy = lane_gather(accX.F, tr_lane_of<16>(pp & 15, NP == 32 ? (pp >> 4) : 0));
+        // H += J^T S J (odometer.cpp:428-472 with sd_k = Gx cx_k + Gy cy_k), lane = point; coefficients are zero beyond
+        // the wave's points. Same arithmetic as k_ref8.
+        float uj[6], vj[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          uj[j] = __builtin_fmaf(cx[j], sxx, cy[j] * sxy);
+          vj[j] = __builtin_fmaf(cx[j], sxy, cy[j] * syy);
+        }
+        const bool cntl = lane < NP;
+        float accH = 0.0f;
+        int jk = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int k = j; k < 6; ++k, ++jk) {
+            const float h = wave_sum_dpp(cntl ? __builtin_fmaf(cx[k], uj[j], cy[k] * vj[j]) : 0.0f);
+            accH = lane == jk ? h : accH;
+          }
+        if (lane < 32) sPartH[wave][lane] = lane < kHUnique ? accH : 0.0f;
+      }
+      // every lane: the six coefficients of ITS (patch, A|B)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float vx = lane_gather(cx[k], my_patch), vy = lane_gather(cy[k], my_patch);
+        c6[k] = (my_patch < cnt && tr_primary_lane<NP>(lane)) ? (my_kind ? vy : vx) : 0.0f;
+      }
+    } else {
+      // ---- templates of this wave's patches (written by the level's setup launch; stale ones included): Gx, Gy into
+      // registers, T into LDS. Buffer loads bounded by the wave's point count (patches beyond it read as zeros: no
+      // branches), Gx / Gy of all patches requested at once straight into the registers they stay in (one memory round
+      // trip for the whole wave), T eight patches at a time (it only passes through)
+      const int nbytes = __builtin_amdgcn_readfirstlane(cnt * 256);
+      auto bounded = [&](const float *q) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(q - lane);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo), 0, nbytes,
+                                                 0x00020000);
+      };
+      const __amdgpu_buffer_rsrc_t rT = bounded(gT), rGx = bounded(gGx), rGy = bounded(gGy);
+      const int loff = lane * 4;
 #pragma unroll
       for (int j = 0; j < kResPPW; ++j) {
-        float t = 0.0f;
-        Gx[j] = 0.0f;
-        Gy[j] = 0.0f;
-        if (j < cnt) {
-          t = __builtin_nontemporal_load(gT + j * 64);
-          Gx[j] = __builtin_nontemporal_load(gGx + j * 64);
-          Gy[j] = __builtin_nontemporal_load(gGy + j * 64);
-        }
-        tw[j * 64] = t;
-        if ((j & 7) == 7) asm volatile("" ::: "memory");  // eight patches' T in flight at a time (they only pass through)
+        Gxy[j].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, loff, j * 256, 2));  // slc: streamed
+        Gxy[j].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, loff, j * 256, 2));
+      }
+#pragma unroll
+      for (int j0 = 0; j0 < kResPPW; j0 += 8) {
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, loff, (j0 + u) * 256, 2));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tw[(j0 + u) * 64] = t8[u];
+      }
+      // every lane: the six coefficients of ITS (patch, A|B): cx_k of point my_patch for an A lane, cy_k for a B lane
+      // (odometer.cpp:313-326; zeros beyond the wave's points)
+      if (my_patch < cnt && tr_primary_lane<NP>(lane)) {
+        const float *cl = e.coef + ((size_t)b * M + i0 + my_patch) * kCoefStride + (my_kind ? 6 : 0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cl[k];
       }
     }
-    // ---- lane l < 32: point i0 + l (X, Y, Z stay in registers). Every lane: the six coefficients of ITS (patch, A|B):
-    // cx_k of point my_patch for an A lane, cy_k for a B lane (odometer.cpp:313-326; zeros beyond the wave's points)
-    const bool pv = lane < cnt;
+    // ---- lane l < NP: point i0 + l (X, Y, Z stay in registers)
     float X = 0.0f, Y = 0.0f, Z = 1.0f;
     if (pv) {
       const float *p3 = e.pt3d + (size_t)b * 3 * M;
       X = p3[i0 + lane], Y = p3[i0 + lane + M], Z = p3[i0 + lane + 2 * M];
     }
-    float c6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (my_patch < cnt && tr_primary_lane<NP>(lane)) {
-      const float *cl = e.coef + ((size_t)b * M + i0 + my_patch) * kCoefStride + (my_kind ? 6 : 0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) c6[k] = cl[k];
-    }
     if (tid < 12) sG[tid] = gst.G[tid];
     __syncthreads();
+    if constexpr (FUSED) {  // the workgroup's part of H -> the pair's H box (the solver workgroup sums and factors it)
+      if (wave == 0 && lane < kHUnique) {
+        const float hv = (sPartH[0][lane] + sPartH[1][lane]) + (sPartH[2][lane] + sPartH[3][lane]);
+        __hip_atomic_store(hbox + (size_t)part * kResHSlot + lane,
+                           ((unsigned long long)(a.tag0 + (unsigned)round + 1u) << 32) |
+                               (unsigned long long)__builtin_bit_cast(unsigned, hv),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
 
     while (active) {  // uniform over the pair's workgroups: every one of them follows the same broadcast
       RES_MARK(0)  // worker: barrier behind the broadcast
@@ -535,8 +761,14 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
       // transposing reduction: a patch's (A, B) pair merges on lane bit 2, then a binary counter of pending registers
       ResWin W[kResD];
       auto issue = [&](int j) {
-        if (a.abl == 2 && j >= kResD) return;
-        const int soff = a.abl == 1 ? 0 : rlane(base_v, j);
+#if defined(ICTR_RES_ABL) && ICTR_RES_ABL == 2  // timing ablations (diagnostic builds, wrong results): no window loads in the loop
+        if (j >= kResD) return;
+#endif
+#if defined(ICTR_RES_ABL) && ICTR_RES_ABL == 1  // ... every window = the plane's first (cache-resident)
+        const int soff = 0;
+#else
+        const int soff = rlane(base_v, j);
+#endif
         W[j % kResD].cd = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_cd, soff, 0));
         W[j % kResD].ab = __builtin_bit_cast(f32x2_a4, __builtin_amdgcn_raw_buffer_load_b64(rcur, (int)off_ab, soff, 0));
       };
@@ -555,10 +787,14 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
           t_n = tw[(j + 1) * 64];
         }
         const ResWin w = W[j % kResD];
-        const float inew = wv.y * w.ab.y + wv.x * w.ab.x + wv.w * w.cd.y + wv.z * w.cd.x;
+        // w0 a + w1 b + w2 c + w3 d in the reference's order; the four products as two packed multiplies (each product
+        // rounded on its own, like the scalar form)
+        const f32x2_t pab = f32x2_t{wv.x, wv.y} * f32x2_t{w.ab.x, w.ab.y}, pcd = f32x2_t{wv.z, wv.w} * f32x2_t{w.cd.x, w.cd.y};
+        const float inew = ((pab.y + pab.x) + pcd.y) + pcd.x;
         if constexpr (j + kResD < kResPPW) issue(j + kResD);
         const float r = t - inew;  // pdiff (odometer.cpp:381); visibility is applied to the patch sums below
-        acc.template push<j>(Gx[j] * r, Gy[j] * r, lane);
+        const f32x2_t gr = Gxy[j] * f32x2_t{r, r};
+        acc.template push<j>(gr.x, gr.y, lane);
       });
       const float F = acc.F;
       RES_MARK(2)  // worker: stage 2
@@ -624,42 +860,33 @@ extern "C" int ictr_prof_res_trace(unsigned long long *out, int clear) {  // out
 }
 #endif
 size_t resident_mail_bytes(int parts, int slots) {
-  return sizeof(unsigned long long) * (size_t)slots * ((size_t)2 * parts * kResSlot + 2 * 16);
+  return sizeof(unsigned long long) * (size_t)slots * res_slot_granules(parts);
 }
 int resident_points_per_workgroup(int np) { return kResWaves * np; }
-// workgroups of this kernel that one CU holds at once (0: the kernel cannot run)
-int resident_blocks_per_cu(int np) {
-  static const int n[2] = {
-      [] {
-        int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void *>(&k_level_resident<16>),
-                                                         kResThreads, 0) != hipSuccess) {
-          (void)hipGetLastError();
-          v = 0;
-        }
-        return v;
-      }(),
-      [] {
-        int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void *>(&k_level_resident<32>),
-                                                         kResThreads, 0) != hipSuccess) {
-          (void)hipGetLastError();
-          v = 0;
-        }
-        return v;
-      }()};
-  return n[np == 32 ? 1 : 0];
+template <int NP, bool FUSED>
+static int res_occupancy() {
+  int v = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void *>(&k_level_resident<NP, FUSED>),
+                                                   kResThreads, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    v = 0;
+  }
+  return v;
 }
-hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int np, int parts, int slots, int nblk,
-                                 unsigned tag0, unsigned long long limit, unsigned long long *mail, int *err,
+// workgroups of this kernel that one CU holds at once (0: the kernel cannot run)
+int resident_blocks_per_cu(int np, int fused) {
+  static const int n[4] = {res_occupancy<16, false>(), res_occupancy<32, false>(), res_occupancy<16, true>(),
+                           res_occupancy<32, true>()};
+  return n[(np == 32 ? 1 : 0) + (fused ? 2 : 0)];
+}
+hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int np, int fused, int parts, int slots,
+                                 int nblk, unsigned tag0, unsigned long long limit, unsigned long long *mail, int *err,
                                  int dbg_mute, int prio_mode, hipStream_t s) {
   ResArgs a;
   a.prio_mode = prio_mode;
   {
     const char *ps = getenv("ICTR_RESIDENT_STAGGER");
     a.stagger = ps ? atoi(ps) : 0;
-    ps = getenv("ICTR_RES_ABL");
-    a.abl = ps ? atoi(ps) : 0;
   }
   {
     const char *ps = getenv("ICTR_RES_PROF_SLOT");
@@ -675,10 +902,15 @@ hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int lev
   a.limit = limit;
   a.mail = mail;
   a.err = err;
-  if (np == 32)
-    hipLaunchKernelGGL(k_level_resident<32>, dim3((parts + 1) * slots), dim3(kResThreads), 0, s, e, a);
+  const dim3 grid((parts + 1) * slots), blk(kResThreads);
+  if (np == 32 && fused)
+    hipLaunchKernelGGL((k_level_resident<32, true>), grid, blk, 0, s, e, a);
+  else if (np == 32)
+    hipLaunchKernelGGL((k_level_resident<32, false>), grid, blk, 0, s, e, a);
+  else if (fused)
+    hipLaunchKernelGGL((k_level_resident<16, true>), grid, blk, 0, s, e, a);
   else
-    hipLaunchKernelGGL(k_level_resident<16>, dim3((parts + 1) * slots), dim3(kResThreads), 0, s, e, a);
+    hipLaunchKernelGGL((k_level_resident<16, false>), grid, blk, 0, s, e, a);
   return hipGetLastError();
 }
 
