@@ -1,4 +1,4 @@
-// ctr_shim.hpp -- header-only C++ facade: namespace CTR { optparam, CamClass, PoseClass, OdometerClass } with the
+// ctr_shim.hpp -- header-only C++ facade: namespace CTR { optparam, CamClass, PoseClass, OdometerClass, util_* } with the
 // reference's method names and argument order (camera.h:19-31, pose.h:18-40, odometer.h:21-30), implemented on the
 // C-ABI of include/ictr.h. A driver written against the reference's classes (run_io_reprojection_test.cpp:189-223,
 // run_track_nposes.cpp:185-259) compiles against this header after two mechanical edits that the missing OpenCV
@@ -42,6 +42,27 @@ class Pyramid {
 // utilities.cpp:14-52
 inline Pyramid *util_constructpyramide(const float *img, int w, int h, int lv_f, bool getgrad, int imgpadding) {
   return new Pyramid(img, w, h, lv_f, getgrad, imgpadding);
+}
+// utilities.cpp:55-113 / 115-189: one psz x psz patch around mid = (x, y) of a pyramid level (bilinear, patch-constant
+// weights; mean subtracted when op->dopatchnorm). The reference takes the level's padded plane and its row stride
+// (`img_ao_pyr[i][level]`, `camobj.getsw(level)`); the device-resident Pyramid carries both, so the call names the
+// level instead. `out` points at psz * psz floats, row-major (what the reference's Eigen::Map refers to).
+inline void util_getPatch(const Pyramid &pyr, int level, const float *mid, float *out, const optparam *op) {
+  check(ictr_get_patch(pyr.handle(), level, mid, 1, op->psz, op->dopatchnorm ? 1 : 0, out), "util_getPatch");
+}
+inline void util_getPatch_grad(const Pyramid &pyr, int level, const float *mid, float *out, float *out_dx, float *out_dy,
+                               const optparam *op) {
+  check(ictr_get_patch_grad(pyr.handle(), level, mid, 1, op->psz, op->dopatchnorm ? 1 : 0, out, out_dx, out_dy),
+        "util_getPatch_grad");
+}
+// run_track_nposes.cpp:271-355 for all points of a pose sample at once (fetch, zero-mean, unit norm, the two dot
+// products, the weighting and the validity tests on the device): mids = x_back[K] y_back[K] x_ref[K] y_ref[K] x_fwd[K]
+// y_fwd[K] at `level`; out_corr[K]. A caller may also restate those lines literally on util_getPatch (tests/cxx/
+// nposes_driver.cpp does both and compares).
+inline void util_patchNCC(const Pyramid &back, const Pyramid &ref, const Pyramid &fwd, int level, const float *mids,
+                          int npoints, const optparam *op, float w_back, float w_fwd, float *out_corr) {
+  check(ictr_ncc_score(back.handle(), ref.handle(), fwd.handle(), level, mids, npoints, op->psz, w_back, w_fwd, out_corr),
+        "util_patchNCC");
 }
 template <typename T> inline void util_SE3_coeff_to_group(T *G, const T *p);
 template <> inline void util_SE3_coeff_to_group<float>(float *G, const float *p) { ictr_se3_coeff_to_group_f(G, p); }

@@ -56,6 +56,7 @@ struct T1Team {
   unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
   unsigned long long *mail;  // [B][2][team][32] granules
   int *err;                  // sticky time-out flag (pinned host memory as the device sees it)
+  int mute;                  // debug (variant bit 25): part `mute - 1` never posts its values (time-out test); 0 = off
 };
 
 struct DevTrace {

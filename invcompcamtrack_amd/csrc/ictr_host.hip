@@ -1384,6 +1384,11 @@ static int team_launch(int weight, hipStream_t s, F &&launch) {
   return ICTR_OK;
 }
 
+// bound of an in-launch poll (team form, resident-iteration form), seconds. Read at every launch: tests shorten it
+static double team_timeout_s() {
+  const char *s = getenv("ICTR_TEAM_TIMEOUT_S");
+  return s ? std::max(0.001, atof(s)) : 5.0;
+}
 // mailbox, tag epoch and error flag of the next team launch (tm->team == 1: not a team launch, nothing allocated)
 static int team_prepare(ictr_batch *b, T1Team *tm) {
   memset(tm, 0, sizeof(*tm));
@@ -1422,11 +1427,9 @@ static int team_prepare(ictr_batch *b, T1Team *tm) {
     HIPCHK(hipMemsetAsync(b->d_team_mail, 0, b->team_mail_bytes, b->stream));
     b->team_epoch = 1;
   }
-  static const double limit_s = [] {
-    const char *s = getenv("ICTR_TEAM_TIMEOUT_S");
-    return s ? std::max(0.001, atof(s)) : 5.0;
-  }();
+  const double limit_s = team_timeout_s();
   tm->tag0 = b->team_epoch << 12;
+  tm->mute = (engine_variant(b) & (1 << 25)) ? 1 : 0;  // debug: part 0 never posts (the time-out path's test)
   tm->limit = (unsigned long long)(limit_s * 1e8);
   tm->mail = b->d_team_mail;
   tm->err = b->d_team_err;
@@ -1552,10 +1555,7 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
     HIPCHK(hipMemsetAsync(b->d_res_mail, 0, b->res_mail_bytes, s));
     b->res_epoch = 1;
   }
-  static const double limit_s = [] {
-    const char *t = getenv("ICTR_TEAM_TIMEOUT_S");
-    return t ? std::max(0.001, atof(t)) : 5.0;
-  }();
+  const double limit_s = team_timeout_s();
   // every workgroup of the launch must be resident: it starts when its slots are free of team / resident launches
   const int bpc = std::max(1, std::min(4, resident_blocks_per_cu(p.np, p.fused)));
   const int weight = p.slots * (p.parts + 1) * (4 / bpc);
@@ -1676,6 +1676,12 @@ static int enqueue_levels(ictr_batch *b) {
 // its arguments (T1Args in ictr_track1.hip) and writes the final states to the mirror itself: no upload copies, no fill,
 // no projection launch, no read-back copy. Variant bit 18 (262144) keeps the separate operations (A/B).
 static int track_enqueue(ictr_batch *b) {
+  if (b->h_team_err && *(volatile int *)b->h_team_err) {
+    // the previous tracking of this batch ran into an exchange time-out (reported by its wait): let whatever it left on
+    // the stream finish, then start clean -- mailbox tags carry the launch epoch, nothing of the failed launch survives
+    HIPCHK(hipStreamSynchronize(b->stream));
+    *(volatile int *)b->h_team_err = 0;
+  }
   bool fused = false;
   if (!b->projected) {
     if (int rc = begin_prepare(b)) return rc;
@@ -1725,16 +1731,24 @@ extern "C" int ictr_batch_track_async(ictr_batch *b) {
   b->projected = false;  // a batch tracking always starts from the poses of the last SetPose calls
   return track_enqueue(b);
 }
+// an in-launch exchange of the last tracking timed out (team form of the one-launch tracker, resident-iteration form):
+// its results are invalid. The flag stays set until the next tracking is enqueued (track_enqueue).
+static int team_error_check(const ictr_batch *b) {
+  if (b->h_team_err && *(volatile int *)b->h_team_err)
+    return fail(ICTR_ERR_HIP, "%s: a workgroup waited in vain for its peers' partial sums (in-launch exchange timed out "
+                              "after %.3f s; are all workgroups of the launch resident?); the results of this tracking "
+                              "are invalid",
+                b->last_path == 4 ? "resident-iteration form (k_level_resident)" : "one-launch tracker, team form (k_track1_p8)",
+                team_timeout_s());
+  return ICTR_OK;
+}
 // wait for the engine's last tracking (not for whatever else was enqueued on the stream after it)
 static int batch_wait(ictr_batch *b) {
   if (b->done_valid)
     HIPCHK(hipEventSynchronize(b->done_ev));
   else
     HIPCHK(hipStreamSynchronize(b->stream));
-  if (b->h_team_err && *(volatile int *)b->h_team_err)
-    return fail(ICTR_ERR_HIP, "one-launch tracker, team form: a workgroup waited in vain for its team's partial sums "
-                              "(time-out); the results of this batch are invalid");
-  return ICTR_OK;
+  return team_error_check(b);
 }
 
 extern "C" int ictr_batch_set_timing(ictr_batch *b, int enable) {
@@ -1850,6 +1864,7 @@ static int batch_fetch_state(ictr_batch *b) {
     HIPCHK(hipMemcpyAsync(b->h_st.data(), b->d_st, sizeof(ProbState) * b->B, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
   }
+  if (int rc = team_error_check(b)) return rc;  // never hand out the poses of a tracking whose exchanges timed out
   for (int i = 0; i < b->B; ++i) {
     memcpy(b->probs[i].p, b->h_st[i].p, sizeof(float) * 6);
     memcpy(b->probs[i].G, b->h_st[i].G, sizeof(float) * 12);

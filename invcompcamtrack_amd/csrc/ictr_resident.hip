@@ -69,7 +69,8 @@ struct ResPoll {
   int dead;
 };
 // poll up to eight granules per lane until every tag matches; lanes / entries without a granule pass nullptr
-// (entries written out one by one: everything stays in registers)
+// (entries written out one by one: everything stays in registers). TWO sets of requests are kept in flight, half a
+// round trip apart: a granule is seen at most half a memory round trip after it became visible (one set: a whole one).
 #define RES_EACH8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 __device__ __forceinline__ void res_poll(ResPoll &pc, const unsigned long long *(&src)[8], unsigned long long (&g)[8],
                                          unsigned tag, int lane) {
@@ -77,6 +78,10 @@ __device__ __forceinline__ void res_poll(ResPoll &pc, const unsigned long long *
 #define RES_LOAD(u) g[u] = src[u] ? __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : empty;
   RES_EACH8(RES_LOAD)
   if (pc.dead) return;
+  unsigned long long h[8];
+  __builtin_amdgcn_s_sleep(4);
+#define RES_LOADH(u) h[u] = src[u] ? __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : empty;
+  RES_EACH8(RES_LOADH)
   bool started = false;
   unsigned long long t0 = 0;
   for (;;) {
@@ -92,16 +97,24 @@ __device__ __forceinline__ void res_poll(ResPoll &pc, const unsigned long long *
       pc.dead = 1;
       break;
     }
-    __builtin_amdgcn_s_sleep(1);
-#define RES_RELOAD(u) \
-  if ((unsigned)(g[u] >> 32) != tag) g[u] = __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    RES_EACH8(RES_RELOAD)
+    // the older set's answers replace what is still missing; that set is requested again for what is missing then
+#define RES_ROTATE(u)                                                                                         \
+  if ((unsigned)(g[u] >> 32) != tag) {                                                                        \
+    g[u] = h[u];                                                                                              \
+    h[u] = __hip_atomic_load(src[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             \
+  }
+    RES_EACH8(RES_ROTATE)
   }
 }
-// one granule per lane (the workers' wait for the broadcast)
+// one granule per lane (the workers' wait for the broadcast): three requests in flight
 __device__ __forceinline__ unsigned long long res_poll1(ResPoll &pc, const unsigned long long *src, unsigned tag, int lane) {
-  unsigned long long g = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag << 32;
+  const unsigned long long empty = (unsigned long long)tag << 32;
+  unsigned long long g = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : empty;
   if (pc.dead) return g;
+  __builtin_amdgcn_s_sleep(3);
+  unsigned long long h1 = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : empty;
+  __builtin_amdgcn_s_sleep(3);
+  unsigned long long h2 = src ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : empty;
   bool started = false;
   unsigned long long t0 = 0;
   while (__builtin_amdgcn_ballot_w64((unsigned)(g >> 32) != tag) != 0) {
@@ -113,8 +126,11 @@ __device__ __forceinline__ unsigned long long res_poll1(ResPoll &pc, const unsig
       pc.dead = 1;
       break;
     }
-    __builtin_amdgcn_s_sleep(1);
-    if ((unsigned)(g >> 32) != tag) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(g >> 32) != tag) {
+      g = h1;
+      h1 = h2;
+      h2 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   return g;
 }

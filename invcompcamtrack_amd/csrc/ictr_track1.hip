@@ -61,6 +61,8 @@ struct T1Args {
   unsigned long long team_limit;   // polling limit in wall_clock64 ticks (100 MHz)
   unsigned long long *team_mail;   // [B][2][team][kTeamSlot] granules {float bits, tag}
   int *team_err;                   // sticky flag (pinned host memory): an exchange timed out
+  int team_mute;                   // debug (variant bit 25): part `team_mute - 1` of every problem never posts its values
+                                   // (its peers' polls run into the limit: the time-out path's test); 0 = off
   __attribute__((aligned(8))) unsigned blob[kT1BlobWords];  // [ProbState x B][PlaneSet x B x nlev]
 };
 
@@ -481,6 +483,7 @@ struct TeamCtx {
   unsigned long long limit;
   int *err;
   int dead;                  // a poll timed out: never wait again
+  int mute;                  // debug: this workgroup never posts (time-out test)
 };
 __device__ __forceinline__ double lane_gather64(double v, int src_lane) {
   const int lo = lane_gather(__double2loint(v), src_lane), hi = lane_gather(__double2hiint(v), src_lane);
@@ -496,7 +499,7 @@ __device__ __forceinline__ double team_allsum(TeamCtx &c, float v, int lane) {
   c.seq += 1;
   const unsigned tag = c.tag0 + c.seq;
   unsigned long long *slot = c.mail + (size_t)(c.seq & 1u) * c.team * kTeamSlot;
-  if (lane < N)
+  if (lane < N && !c.mute)
     __hip_atomic_store(slot + c.part * kTeamSlot + lane,
                        ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(64 * kT8MaxWaves, LEAN ? 4 : 2) void k_track1_p8(En
     tc.limit = a.team_limit;
     tc.err = a.team_err;
     tc.dead = 0;
+    tc.mute = (a.team_mute != 0 && part + 1 == a.team_mute) ? 1 : 0;
   }
   SolveOpts sopt = solve_opts(e);
   sopt.robust = 0;  // the host routes every behaviour-changing option to the any-size form: no compose / log code here
@@ -1035,6 +1039,7 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
   a.team_limit = team > 1 ? tm->limit : 0;
   a.team_mail = team > 1 ? tm->mail : nullptr;
   a.team_err = team > 1 ? tm->err : nullptr;
+  a.team_mute = team > 1 ? tm->mute : 0;
   if (team > 1) {
     if (team > kTeamMax || !tm->mail || !tm->err || (long long)tm->q * team < maxpts) return hipErrorInvalidValue;
     maxpts = std::min(maxpts, tm->q);  // LDS records and patches: this workgroup's share only

@@ -85,6 +85,13 @@ def test_cxx_facade_compiles_against_the_c_abi(tmp_path):
            "-l:libictr_hip.so", "-Wl,-rpath,$ORIGIN/../../invcompcamtrack_amd"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # the native run_track_nposes caller (run_track_nposes.cpp:133-361 on the facade, util_getPatch / util_patchNCC included)
+    exe2 = os.path.join(ROOT, "tests", "cxx", "nposes_driver")
+    cmd2 = ["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe2,
+            os.path.join(ROOT, "tests", "cxx", "nposes_driver.cpp"), "-L" + os.path.join(ROOT, "invcompcamtrack_amd"),
+            "-l:libictr_hip.so", "-Wl,-rpath,$ORIGIN/../../invcompcamtrack_amd"]
+    r = subprocess.run(cmd2, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     # a plain C translation unit can include the ABI header too
     c = tmp_path / "abi.c"
     c.write_text('#include "ictr.h"\nint main(void){ ictr_optparam op; return ictr_optparam_init(&op,1,0,8,5,0.1f,0,0,10,0) + (int)sizeof(op) - 44; }\n')

@@ -145,6 +145,19 @@ def test_run_track_nposes_matches_serial_oracle(oracle, tmp_path, dopatchnorm):
         assert corr_g[sid].shape == (len(inl[sid]),)
         assert np.abs(corr_g[sid] - corr_o[sid]).max() <= 2e-3  # printed with 3 significant digits
         assert corr_g[sid].min() >= 0.0 and np.median(corr_g[sid]) > 0.9
+    # the NATIVE caller (tests/cxx/nposes_driver.cpp: run_track_nposes.cpp:133-361 restated on include/ctr_shim.hpp with
+    # the reference's control flow -- one OdometerClass for all samples, util_getPatch / NCC through the facade): the
+    # same output file byte for byte, and its literal restatement of the NCC lines on util_getPatch agrees with the
+    # device score
+    exe = os.path.join(ROOT, "tests", "cxx", "nposes_driver")
+    if os.path.exists(exe):
+        fout3 = str(tmp_path / "outfileRANSAC_native.txt")
+        r = subprocess.run([exe, fin, fout3, "--check"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "max |NCC restated" in r.stderr
+        assert open(fout3).read() == open(fout).read()
+    else:
+        pytest.skip("tests/cxx/nposes_driver not built (run the CPU tests first)")
     # --gpus 2: the samples split over two ranks (here both on the one GPU of the box), merged by rank 0: same file
     fout2 = str(tmp_path / "outfileRANSAC_2ranks.txt")
     assert drv_np.main([fin, fout2, "--gpus", "2"]) == 0
