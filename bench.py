@@ -80,6 +80,11 @@ def parse():
                     help="sharded mode: also try the library's own in-stream RCCL communicator (dist.RcclDirect)")
     ap.add_argument("--p2p", action="store_true",
                     help="sharded mode: also try the one-shot peer-to-peer exchange of the 27-float records (dist.P2PDirect)")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: STRONG scaling -- ONE set of 32 400 points per frame pair, split over the ranks in "
+                         "contiguous blocks (dist.shard_slices; the north star's partition: the patches of one frame "
+                         "shard across the GPUs), so the per-iteration all-reduce is exposed instead of amortised; "
+                         "value keeps its unit (whole-job aligned Mpix/s), \"scaling\": \"strong\"")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (sharded phases + collectives) with a world of 1 (testing)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
@@ -163,17 +168,22 @@ def build_inputs(args, rank, world):
                                        tex_seed=1234 + s,
                                        dp_gt=np.array([0.02, -0.015, 0.03, 0.003, -0.002, 0.004]) * (1 + 0.5 * s)))
     n_pts = scenes[0]["pts3d"].shape[1]
-    op = ic.optparam(lv_f, 0, P, args.maxiter, 0.0, 0, 0, n_pts)
+    lo, hi = 0, n_pts
+    if args.strong:  # this rank's block of every pair's points (the same points on every rank before the split)
+        from invcompcamtrack_amd.dist import shard_slices
+        lo, hi = shard_slices(n_pts, world)[rank]
+        n_pts = hi - lo
+    op = ic.optparam(lv_f, 0, P, args.maxiter, 0.0, 0, 0, max(n_pts, 1))
     cam = ic.CamClass(lv_f + 1, scenes[0]["fc"], scenes[0]["cc"], scenes[0]["wh"], P)
     pyrs, points = [], []
-    rng = np.random.default_rng(7 + rank)
+    rng = np.random.default_rng(7 + (0 if args.strong else rank))
     for b in range(args.batch):
         sc = scenes[b % 2]
         pyrs.append((ic.Pyramid(sc["img_a"], lv_f, P), ic.Pyramid(sc["img_b"], lv_f, P)))
         pts = sc["pts3d"].copy()
-        if world > 1 or b >= 2:  # every rank / problem owns a different jittered sample of the same plane
+        if (world > 1 and not args.strong) or b >= 2:  # every rank / problem owns a different jittered sample of the same plane
             pts = pts + rng.normal(0, 1e-3, pts.shape) * np.array([[1.0], [1.0], [0.0]])
-        points.append(np.ascontiguousarray(pts))
+        points.append(np.ascontiguousarray(pts[:, lo:hi]))
 
     def make_engines(n_parts, split, variant=None):
         """split=False: n_parts engines that each hold all B pairs (they take the steps in turn);
@@ -587,14 +597,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.strong and sharded) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "R1080p-dense-se3: reference-faithful 6-DoF SE(3) tracker, "
                                    f"{args.width}x{args.height}, {args.levels}-level pyramid, {n_pts} 8x8 patches "
                                    "tiling the frame, maxiter 10 fixed",
-                       "frame_pairs_per_step_per_gpu": B, "points_per_pair_per_gpu": n_pts, "psz": P,
+                       "frame_pairs_per_step_per_gpu": B, "points_per_pair_per_gpu": n_pts,
+                       "points_per_pair_whole_job": n_pts * world if (args.strong and sharded) else None, "psz": P,
                        "levels": args.levels, "maxiter": args.maxiter, "normdp_ratio": 0.0,
                        "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
                        "host_pipeline": ("2 step holders alternate, host one step ahead"

@@ -448,6 +448,19 @@ class ShardedTracker:
 
     def poses(self):
         out = np.concatenate([b.poses() for b in self.batches], 0)
-        if self.p2p is not None and any(c.error() for c in self.p2p):
-            raise RuntimeError("P2P exchange timed out: a peer did not deliver its records (results are invalid)")
+        if self.p2p is not None:
+            # A time-out is local knowledge: the rank whose mailbox filled in time saw nothing wrong, while the peer that
+            # waited in vain went on with a wrong sum -- the lock-step solves have diverged and every later exchange
+            # would carry the damage on. All ranks therefore agree on the verdict (one MIN all-reduce on the torch group,
+            # every rank calls it at this point whatever it saw), and on a failure ALL of them drop the mailboxes
+            # (torch.distributed serves the next tracking) and raise.
+            ok = not any(c.error() for c in self.p2p)
+            if not _agree(self._torch, self._dist, self.group, ok):
+                self._torch.cuda.synchronize()
+                for c in self.p2p:
+                    c.close()
+                self.p2p = None
+                raise RuntimeError("P2P exchange timed out on " + ("this rank" if not ok else "a peer rank") +
+                                   ": a rank did not receive its peers' records in time; the results of this tracking "
+                                   "are invalid on EVERY rank (the mailboxes are closed, torch.distributed takes over)")
         return out

@@ -19,7 +19,7 @@ from ._lib import check, fp
 from .classoftrack import oftrack
 from .tracker import Pyramid
 
-__all__ = ["track_points", "dense_flow", "good_features", "run_OF_point_track", "last_kernel_ms"]
+__all__ = ["track_points", "partition_patches", "dense_flow", "good_features", "run_OF_point_track", "last_kernel_ms"]
 
 
 def last_kernel_ms():
@@ -28,10 +28,41 @@ def last_kernel_ms():
     return ms if ms >= 0 else None
 
 
-def track_points(pyr_a, pyr_b, pts, psz=15, lv_f=None, lv_l=0, maxiter=10, eps=0.01):
+def partition_patches(npatches, world):
+    """Contiguous, balanced patch ranges: rank r owns [lo, hi). The patches are mutually independent (each owns its two
+    parameters: SURVEY.md §8e, BASELINE config 4), so this axis needs no collective in the data path."""
+    base, rem = divmod(npatches, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def track_points(pyr_a, pyr_b, pts, psz=15, lv_f=None, lv_l=0, maxiter=10, eps=0.01, dist=None, group=None, _local=None):
     """Track K points from frame A to frame B. pts: (K,2) level-0 pixel coordinates (x,y).
-    Returns (new_pts (K,2) float32 with NaN rows for lost points, status (K,) bool, iters (K,) int32)."""
+    Returns (new_pts (K,2) float32 with NaN rows for lost points, status (K,) bool, iters (K,) int32).
+
+    dist (torch.distributed, initialised; optional `group`): BASELINE config 4's multi-GPU form -- every rank holds both
+    frames (its own pyramids on its own GPU) and tracks the contiguous range partition_patches(K, world)[rank] of the K
+    patches; rank 0 gathers the ranges in rank order and returns the full arrays, the other ranks return None. The
+    result on rank 0 equals the single-process result bit for bit (a patch's arithmetic does not depend on what else
+    is in its launch). `_local` replaces the GPU call in the CPU tests of the partition / gather logic."""
     pts = np.atleast_2d(np.asarray(pts, np.float32))
+    if dist is not None:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        lo, hi = partition_patches(pts.shape[0], world)[rank]
+        local = _local if _local is not None else (
+            lambda q: track_points(pyr_a, pyr_b, q, psz, lv_f, lv_l, maxiter, eps) if len(q) else
+            (np.zeros((0, 2), np.float32), np.zeros(0, bool), np.zeros(0, np.int32)))
+        mine = local(pts[lo:hi])
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0, group=group)
+        if rank != 0:
+            return None
+        return (np.concatenate([q[0] for q in parts], 0), np.concatenate([q[1] for q in parts], 0),
+                np.concatenate([q[2] for q in parts], 0))
     K = pts.shape[0]
     lv_f = pyr_a.lv_f if lv_f is None else lv_f
     soa = np.ascontiguousarray(pts.T)

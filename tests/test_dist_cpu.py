@@ -282,3 +282,49 @@ def test_global_norm_and_sharded_set3dpoints_two_ranks_gloo():
         assert np.array_equal(m, m2) and v == v2 and prob == 3
         assert np.allclose(pts_after, (allp[:, lo:hi] - mean[:, None]) / var)   # normalised in place, global statistics
     assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]     # identical on both ranks
+
+
+def _worker_patchflow(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from invcompcamtrack_amd import patchflow as pf
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pts = np.stack([np.arange(11, dtype=np.float32), 100 + np.arange(11, dtype=np.float32)], 1)
+    seen = []
+
+    def fake_local(qpts):   # stands in for the GPU call: results that identify patch and rank
+        seen.append(qpts.copy())
+        return (qpts + np.float32(0.5), qpts[:, 0] % 2 == 0, np.full(len(qpts), 10 + rank, np.int32))
+    res = pf.track_points(None, None, pts, dist=dist, _local=fake_local)
+    q.put((rank, None if res is None else [np.asarray(x).tolist() for x in res], [s.tolist() for s in seen]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_patchflow_patch_ranges_over_two_ranks_gathered_by_rank0():
+    """BASELINE config 4's multi-GPU form (patchflow.track_points(..., dist=...)): contiguous patch ranges per rank,
+    no data-path collective, rank 0 assembles the full result in patch order; world 2 over gloo, GPU call replaced."""
+    import torch.multiprocessing as mp
+    from invcompcamtrack_amd import patchflow as pf
+    assert pf.partition_patches(11, 2) == [(0, 6), (6, 11)] and pf.partition_patches(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_patchflow, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    got = dict()
+    for _ in range(2):
+        r, res, seen = q.get(timeout=120)
+        got[r] = (res, seen)
+    for p_ in ps:
+        p_.join(60)
+        assert p_.exitcode == 0
+    assert got[1][0] is None
+    new, st, it = (np.asarray(x) for x in got[0][0])
+    assert np.array_equal(new[:, 0], np.arange(11) + 0.5) and np.array_equal(new[:, 1], 100.5 + np.arange(11))
+    assert np.array_equal(st, np.arange(11) % 2 == 0)
+    assert np.array_equal(it, [10] * 6 + [11] * 5)
+    assert np.asarray(got[0][1][0]).shape == (6, 2) and np.asarray(got[1][1][0]).shape == (5, 2)

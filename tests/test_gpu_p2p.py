@@ -176,3 +176,68 @@ def test_sharded_tracker_over_p2p_two_processes_one_gpu():
     ref = eng.poses()
     assert np.abs(res[0][2] - ref).max() <= 2e-5
     assert np.abs(res[0][2] - np.array([sc["p_b"] for sc in scs])).max() < 5e-3
+
+
+def _worker_tracker_late_peer(rank, world, port, q):
+    """Rank 1 enqueues its tracking half a second late under a 0.05 s exchange limit: rank 0's kernel waits in vain
+    (time-out, local flag), rank 1 finds rank 0's records waiting and sees nothing wrong."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["ICTR_P2P_TIMEOUT_S"] = "0.05"
+    import time
+    import torch
+    import torch.distributed as dist
+    import invcompcamtrack_amd as ic
+    from invcompcamtrack_amd import synth
+    from invcompcamtrack_amd.dist import ShardedTracker, shard_slices
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    lv_f, psz = 1, 8
+    sc = synth.make_scene(256, 224, n_points=200, seed=41, margin=12.0)
+    cam = ic.CamClass(lv_f + 1, sc["fc"], sc["cc"], sc["wh"], psz)
+    lo, hi = shard_slices(200, world)[rank]
+    op = ic.optparam(lv_f, 0, psz, 3, 0.0, 0, 0, hi - lo)
+    eng = ic.TrackBatch(cam, op, 1)
+    pa, pb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
+    eng.Set3Dpoints(0, np.ascontiguousarray(sc["pts3d"][:, lo:hi]))
+    eng.SetPose(0, sc["p_a"], pa, pb)
+    tr = ShardedTracker(eng, p2p=True)
+    had_p2p = tr.p2p is not None
+    local_flag, raised, msg = None, False, ""
+    if had_p2p:
+        dist.barrier()
+        if rank == 1:
+            time.sleep(0.5)
+        tr.track()
+        torch.cuda.synchronize()
+        local_flag = any(c.error() for c in tr.p2p)
+        try:
+            tr.poses()
+        except RuntimeError as exc:
+            raised, msg = True, str(exc)
+    q.put((rank, had_p2p, local_flag, raised, msg, tr.p2p is None))
+    tr.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_p2p_timeout_on_one_rank_fails_the_tracking_on_every_rank():
+    """a P2P time-out is local knowledge. The ranks agree on the verdict in poses(): BOTH raise, both drop
+    the mailboxes -- also the rank that saw nothing wrong."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tracker_late_peer, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], "P2P path was not available on both ranks"
+    assert res[0][2] is True                  # rank 0 waited in vain
+    assert res[0][3] and res[1][3], res       # ... and BOTH ranks raise
+    assert "timed out" in res[0][4] and "timed out" in res[1][4]
+    assert res[0][5] and res[1][5]            # mailboxes closed on both
