@@ -99,7 +99,12 @@ void ictr_solve6(const float *H36, const float *b6, float *x6);
 /* ------------------------------------------------------------------ util_constructpyramide (utilities.cpp:14-52) */
 typedef struct ictr_pyramid ictr_pyramid;
 /* img: host, row-major f32, w x h. Builds lv_f+1 levels on the device: 2x2 box down-sampling, [-1 0 1]
- * gradients with reflect-101 border, replicate (image) / zero (gradient) padding by `pad` pixels. */
+ * gradients with reflect-101 border, replicate (image) / zero (gradient) padding by `pad` pixels.
+ * getgrad: 0 image levels only (a "new" frame); 1 image + gradient planes (the reference's getgrad = true); 2 image
+ * levels only, to be used as a REFERENCE frame: the tracker's 8x8 setup kernel forms the gradient patches on the fly
+ * from the image plane (same subtraction, same blend, same bits as with the planes) -- a quarter of the memory and of
+ * the build's bytes; accepted by trackings that run the 8x8 per-iteration / resident forms (psz 8, no robustness
+ * option, more points than the one-launch tracker takes), refused with ICTR_ERR_STATE elsewhere. */
 int ictr_pyramid_create(ictr_pyramid **out, const float *img, int w, int h, int lv_f, int getgrad, int pad);
 /* same, img already in device memory (stays caller-owned; only read during the call) */
 int ictr_pyramid_create_device(ictr_pyramid **out, const float *img_dev, int w, int h, int lv_f, int getgrad,
@@ -203,7 +208,12 @@ int ictr_odometer_get_norm(const ictr_odometer *odo, double *meanshift3, double 
  *   bit 19 (524288) one workgroup per problem in the one-launch tracker (no teams, see ictr_batch_set_team)
  *   bit 21 (2097152) never the resident-iteration form (all iterations of a level in one launch, templates in
  *                  registers: the default for up to 8 dense frame pairs of >= 8193 8x8 patches); bit 23 (8388608) that
- *                  form whatever the batch size */
+ *                  form whatever the batch size; bit 26 (67108864) that form with the level's setup inside the launch
+ *                  (A/B: measured slower); bit 25 (33554432) debug: one workgroup of every problem skips its exchange
+ *                  store (tests of the time-out path: the tracking FAILS)
+ *   bit 27 (134217728) 8x8 setup kernel reads the reference pyramid's gradient planes instead of forming the gradient
+ *                  patches on the fly from its image plane (the default for builder-made pyramids, the only way for
+ *                  pyramids built with getgrad = 2; bit-identical patches either way) */
 int ictr_odometer_set_variant(ictr_odometer *odo, int variant);
 /* one-launch tracker, team form (see ictr_batch_set_team) */
 int ictr_odometer_set_team(ictr_odometer *odo, int target_points, int min_points, int max_points);

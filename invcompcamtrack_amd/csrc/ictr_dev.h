@@ -73,6 +73,9 @@ struct EngineDev {
   int dopatchnorm;
   int sharded;  // 1: accumulate kernels stop after writing rank-local sums to red[]
   int packed;   // 1: every problem's reference pyramid carries the interleaved {img, dx, dy, 0} planes
+  int otf;      // every reference pyramid is builder-made (its gradients ARE the central differences of its image plane):
+                // 1 = the 8x8 setup kernel may form them on the fly from the image plane; 2 = it must (some reference
+                // pyramid is image-only: no dx / dy / packed planes exist); 0 = caller-supplied gradient planes
   // behaviour-changing options, all off by default; any of them routes P = 8 through the
   // any-size kernels. ICTR_ROBUST_CLEAN: a point outside the reference view at a level contributes nothing (its
   // stale patches / gradients are zeroed instead of reused, cf. odometer.cpp:304); ICTR_ROBUST_COMPOSE: G <- exp(dp) G

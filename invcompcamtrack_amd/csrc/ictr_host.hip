@@ -297,7 +297,9 @@ static void host_getpose(bool donorm, const float *p_f, const float *G_f, const 
 
 // ---------------------------------------------------------------- pyramid
 struct ictr_pyramid {
-  int nlev = 0, pad = 0, w0 = 0, h0 = 0, getgrad = 0;
+  int nlev = 0, pad = 0, w0 = 0, h0 = 0, getgrad = 0;  // getgrad: 0 image only, 1 + dx / dy / packed planes,
+                                                       // 2 image only, gradients formed on the fly by the consumers
+  int builder_made = 0;  // the planes were computed by pyramid_build (dx / dy ARE the central differences of img)
   std::vector<int> w, h, sw, sh;
   std::vector<float *> img, dx, dy;  // device planes
   std::vector<float *> pack;         // with gradients: the level again as interleaved {img, dx, dy, 0} texels
@@ -320,7 +322,7 @@ extern "C" int ictr_pyramid_view_(const ictr_pyramid *p, ictr_pyramid_view *v) {
   v->img = p->img.data();
   v->dx = p->dx.data();
   v->dy = p->dy.data();
-  v->getgrad = p->getgrad;
+  v->getgrad = p->getgrad == 1 ? 1 : 0;  // (gradient PLANES; image-only pyramids of the tracker's OTF path have none)
   return 0;
 }
 
@@ -339,7 +341,7 @@ static void level_size(int w, int h, int level, int *wl, int *hl) {
 }
 
 static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad, int pad) {
-  if (!out || w < 1 || h < 1 || lv_f < 0 || lv_f > 15 || pad < 0)
+  if (!out || w < 1 || h < 1 || lv_f < 0 || lv_f > 15 || pad < 0 || getgrad < 0 || getgrad > 2)
     return fail(ICTR_ERR_INVALID, "pyramid: bad arguments");
   if (int rc = need_device()) return rc;
   ictr_pyramid *p = new ictr_pyramid;
@@ -362,7 +364,7 @@ static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad
     p->sh.push_back(hl + 2 * pad);
     size_t plane = (size_t)(wl + 2 * pad) * (hl + 2 * pad);
     plane = (plane + 63) / 64 * 64;  // 256-B aligned planes
-    total += plane * (getgrad ? 7 : 3);
+    total += plane * (getgrad == 1 ? 7 : getgrad == 2 ? 1 : 3);
   }
   hipError_t e = hipMalloc((void **)&p->arena, total * sizeof(float));
   if (e != hipSuccess) {
@@ -374,10 +376,10 @@ static int pyramid_alloc(ictr_pyramid **out, int w, int h, int lv_f, int getgrad
     size_t plane = (size_t)p->sw[l] * p->sh[l];
     plane = (plane + 63) / 64 * 64;
     p->img.push_back(cur);
-    p->dx.push_back(cur + plane);
-    p->dy.push_back(cur + 2 * plane);
-    p->pack.push_back(getgrad ? cur + 3 * plane : nullptr);
-    cur += (getgrad ? 7 : 3) * plane;
+    p->dx.push_back(getgrad == 2 ? nullptr : cur + plane);
+    p->dy.push_back(getgrad == 2 ? nullptr : cur + 2 * plane);
+    p->pack.push_back(getgrad == 1 ? cur + 3 * plane : nullptr);
+    cur += (getgrad == 1 ? 7 : getgrad == 2 ? 1 : 3) * plane;
   }
   *out = p;
   return ICTR_OK;
@@ -390,14 +392,16 @@ static int pyramid_build(ictr_pyramid *p, const float *img_dev, hipStream_t s) {
     const char *v = getenv("ICTR_PYR_UNFUSED");
     return v && atoi(v) != 0;
   }();
+  p->builder_made = 1;
+  const int planes = p->getgrad == 1 ? 1 : 0;  // getgrad 2: the image levels only
   for (int l = 0; l < p->nlev; ++l) {
-    if (!unfused) {
+    if (!unfused || p->getgrad == 2) {
       if (l == 0)
         launch_pyr_level(img_dev, 1, p->w[0], p->h[0], p->w[0], p->img[0], p->dx[0], p->dy[0], p->pack[0], p->w[0],
-                         p->h[0], p->pad, p->sw[0], p->sh[0], p->getgrad, s);
+                         p->h[0], p->pad, p->sw[0], p->sh[0], planes, s);
       else
         launch_pyr_level(p->img[l - 1], 0, p->w[l - 1], p->h[l - 1], p->sw[l - 1], p->img[l], p->dx[l], p->dy[l],
-                         p->pack[l], p->w[l], p->h[l], p->pad, p->sw[l], p->sh[l], p->getgrad, s);
+                         p->pack[l], p->w[l], p->h[l], p->pad, p->sw[l], p->sh[l], planes, s);
       continue;
     }
     if (l == 0)
@@ -517,7 +521,7 @@ static int get_patch_impl(const ictr_pyramid *pyr, int level, const float *mids,
                           float *out, float *out_dx, float *out_dy, bool grad) {
   if (!pyr || level < 0 || level >= pyr->nlev || !mids || !out || K < 0 || psz < 1 || psz > pyr->pad)
     return fail(ICTR_ERR_INVALID, "get_patch: bad arguments (psz must be <= pyramid padding)");
-  if (grad && (!out_dx || !out_dy || !pyr->getgrad)) return fail(ICTR_ERR_INVALID, "get_patch_grad: no gradients");
+  if (grad && (!out_dx || !out_dy || pyr->getgrad != 1)) return fail(ICTR_ERR_INVALID, "get_patch_grad: no gradient planes");
   if (K == 0) return ICTR_OK;
   // centres must lie inside [0,swo] x [0,sho] like the callers guarantee (odometer.cpp:273-276)
   for (int64_t i = 0; i < K; ++i)
@@ -776,6 +780,7 @@ struct ictr_batch {
   int evk_iters = 0;
   bool evk_valid = true;  // the per-iteration kernel events of the last tracking were recorded (not in the resident form)
   int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
+  int otf = 0;       // ... is builder-made (1), and some of them image-only (2): see EngineDev.otf
   int maxpts = 0;    // largest nopoints over the problems of the current tracking (set by ictr_batch_begin)
   int last_path = 0; // 0: per-iteration launches, 1: one-launch tracker (ictr_track1.hip), 2: launches replayed as a graph,
                      // 3: one-launch tracker that also carried the begin phase and wrote the host mirror
@@ -858,6 +863,7 @@ static EngineDev engine_dev(const ictr_batch *b) {
   e.dopatchnorm = b->op->dopatchnorm ? 1 : 0;
   e.sharded = b->sharded;
   e.packed = b->packed;
+  e.otf = b->otf;
   e.robust = b->robust;
   e.huber_k = b->huber_k;
   e.pt3d = b->d_pt3d;
@@ -1090,6 +1096,7 @@ extern "C" int ictr_batch_setpose_all(ictr_batch *b, const double *p_all, const 
   return ICTR_OK;
 }
 
+static bool use_track1(const ictr_batch *b);
 // ictr_batch_begin, host part: initial states, plane table and launch geometry of the coming tracking
 static int begin_prepare(ictr_batch *b) {
   if (int rc = check_op(b->op, b->cam)) return rc;
@@ -1097,7 +1104,7 @@ static int begin_prepare(ictr_batch *b) {
     return fail(ICTR_ERR_STATE, "optparam maxpttrack/psz/lv_f changed after creation");
   b->done_valid = false;
   b->phase_it = 0;
-  bool all_packed = true;
+  bool all_packed = true, all_builder = true, any_image_only = false;
   if (b->timing) std::fill(b->ev_used.begin(), b->ev_used.end(), 0);
   int maxpts = 0;
   for (int i = 0; i < b->B; ++i) {
@@ -1119,8 +1126,12 @@ static int begin_prepare(ictr_batch *b) {
       ps.pack = ph.ref->pack[l];
       if (!ps.pack) all_packed = false;
     }
+    if (!ph.ref->builder_made) all_builder = false;
+    if (ph.ref->getgrad == 2) any_image_only = true;
   }
   b->packed = all_packed ? 1 : 0;
+  b->otf = !all_builder ? 0 : (any_image_only ? 2 : 1);
+
   b->maxpts = maxpts;
   {
     // P=8 fast path geometry: a wave owns `cpw` consecutive points. Small problems get small chunks (more
@@ -1140,6 +1151,10 @@ static int begin_prepare(ictr_batch *b) {
     if (b->gridx8 >= 64 && !getenv("ICTR_NO_XCD_BANDS"))  // multiple of 8: XCD-aware order (xcd_band_block)
       b->gridx8 = (int)std::min<int64_t>((b->gridx8 + 7) / 8 * 8, capx / 8 * 8);
   }
+  if (b->otf == 2 && (b->P != 8 || b->robust || (engine_variant(b) & 2) || use_track1(b)))
+    return fail(ICTR_ERR_STATE, "a reference pyramid without gradient planes (getgrad = 2: gradients formed on the fly) is "
+                                "served by the 8x8 setup kernel k_ref8 only: psz 8, no robustness option, variant bit 1 "
+                                "clear, and a problem size beyond the one-launch tracker's (variant bit 13 forces that)");
   return ICTR_OK;
 }
 // ... device part: upload states + plane table, clear the trace counter, run step 3 for every problem
@@ -1496,7 +1511,7 @@ static ResPlan resident_plan(const ictr_batch *b) {
   static const int on = env_int("ICTR_RESIDENT", 1);
   static const int min_pts = env_int("ICTR_RESIDENT_MINPTS", 8193);  // below: the one-launch tracker's team form
   const int v = engine_variant(b);
-  if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !b->packed)
+  if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !(b->packed || b->otf == 2))
     return p;
   if (b->maxpts < min_pts || b->op->maxiter < 1) return p;
   static const int max_b = env_int("ICTR_RESIDENT_MAXB", 1 << 20);
@@ -2080,7 +2095,7 @@ extern "C" int ictr_patchflow(const ictr_pyramid *pa, const ictr_pyramid *pb, co
     return fail(ICTR_ERR_INVALID, "patchflow: bad arguments (psz must be 1..32)");
   if (lv_f >= pa->nlev || lv_f >= pb->nlev || lv_f > 15)
     return fail(ICTR_ERR_INVALID, "patchflow: pyramids have fewer than lv_f+1 levels");
-  if (!pa->getgrad) return fail(ICTR_ERR_INVALID, "patchflow: the first pyramid needs gradients");
+  if (pa->getgrad != 1) return fail(ICTR_ERR_INVALID, "patchflow: the first pyramid needs gradient planes (getgrad = 1)");
   if (pa->pad < psz || pb->pad < psz) return fail(ICTR_ERR_INVALID, "patchflow: pyramid padding must be >= psz");
   for (int l = lv_l; l <= lv_f; ++l)
     if (pa->w[l] != pb->w[l] || pa->h[l] != pb->h[l] || pa->sw[l] != pb->sw[l])

@@ -645,15 +645,64 @@ __global__ __launch_bounds__(kBlock) void k_iter8(EngineDev e, LevelCam lc, int 
 // of the reference view keeps its stale patch and coefficients (odometer.cpp:304): its S is summed from the stored
 // gradients, so nothing but the patch buffers and the coefficient line carries state from level to level.
 // H is compared to tolerance only (summation order differs from the CPU path's whole-buffer sums anyway).
+// Gradients on the fly (OTF): a pyramid the builder made has dx = I(x+1) - I(x-1), dy = I(y+1) - I(y-1) inside the image,
+// 0 on its border columns / rows (reflect-101) and in the padding (utilities.cpp:30-45), so the blended gradient patches
+// can be formed from the IMAGE plane alone: the same f32 subtraction the builder did, the same blend -- the same bits --
+// from a 4 x 4 neighbourhood per lane (12 texels: two 16-byte and two 8-byte loads) instead of the three planes' taps
+// (or the packed 16-byte texels, a third of which is padding). The reference frame is then read at 4 B per pixel, and a
+// pyramid built for this path (getgrad = 2) holds nothing but the image levels.
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const f32x4_a4 __attribute__((address_space(1))) *gconst_f32x4a;
+struct TapLoadsOTF {
+  f32x4_a4 r0, r1;   // rows y and y-1: columns x-2 .. x+1   (b = r0[1], a = r0[2], d = r1[1], c = r1[2])
+  f32x2_a4 up, dn;   // rows y+1 and y-2: columns x-1, x
+};
+__device__ __forceinline__ TapLoadsOTF taps_issue_otf(gconst_f32 img_at_base, int loff, int sw) {
+  TapLoadsOTF t;
+  gconst_f32 q = img_at_base + loff;
+  t.r0 = *reinterpret_cast<gconst_f32x4a>(q - 2);
+  t.r1 = *reinterpret_cast<gconst_f32x4a>(q - sw - 2);
+  t.up = *reinterpret_cast<gconst_f32x2>(q + sw - 1);
+  t.dn = *reinterpret_cast<gconst_f32x2>(q - 2 * sw - 1);
+  return t;
+}
+// ix, iy: unpadded image coordinates of tap a of this lane's pixel; w, h: the level's size. interior: every tap of
+// every lane of the patch is at least one pixel inside (wave-uniform fast path: no predicates)
+__device__ __forceinline__ void taps_blend_otf(const TapLoadsOTF &t, float w0, float w1, float w2, float w3, bool interior,
+                                               int ix, int iy, int w, int h, float &tv, float &gx, float &gy) {
+  const float a = t.r0[2], b = t.r0[1], c = t.r1[2], d = t.r1[1];
+  tv = w0 * a + w1 * b + w2 * c + w3 * d;
+  float xa = t.r0[3] - t.r0[1], xb = t.r0[2] - t.r0[0], xc = t.r1[3] - t.r1[1], xd = t.r1[2] - t.r1[0];
+  float ya = t.up.y - t.r1[2], yb = t.up.x - t.r1[1], yc = t.r0[2] - t.dn.y, yd = t.r0[1] - t.dn.x;
+  if (!interior) {  // the builder's border rules: dx is 0 outside 1 <= X <= w-2 (and outside the image rows), dy alike
+    const bool colA = ix >= 0 && ix < w, colB = ix - 1 >= 0 && ix - 1 < w, rowA = iy >= 0 && iy < h, rowC = iy - 1 >= 0 && iy - 1 < h;
+    const bool dxA = ix >= 1 && ix <= w - 2, dxB = ix - 1 >= 1 && ix - 1 <= w - 2;
+    const bool dyA = iy >= 1 && iy <= h - 2, dyC = iy - 1 >= 1 && iy - 1 <= h - 2;
+    xa = (dxA && rowA) ? xa : 0.0f;
+    xb = (dxB && rowA) ? xb : 0.0f;
+    xc = (dxA && rowC) ? xc : 0.0f;
+    xd = (dxB && rowC) ? xd : 0.0f;
+    ya = (dyA && colA) ? ya : 0.0f;
+    yb = (dyA && colB) ? yb : 0.0f;
+    yc = (dyC && colA) ? yc : 0.0f;
+    yd = (dyC && colB) ? yd : 0.0f;
+  }
+  gx = w0 * xa + w1 * xb + w2 * xc + w3 * xd;
+  gy = w0 * ya + w1 * yb + w2 * yc + w3 * yd;
+}
+
 template <int kU>
 struct RefLoads {
   TapLoads r[kU], x[kU], y[kU];
   TapLoads4 p4[kU];
+  TapLoadsOTF o[kU];
   int rec[kU];
   int vis[kU];
+  int inner[kU];  // OTF: the patch's taps are all at least one pixel inside the image (wave-uniform)
+  int tx[kU], ty[kU];  // OTF: unpadded coordinates of tap a of pixel (0, 0)
 };
 
-template <bool PN, int kU, bool PK>  // PK: packed {img, dx, dy, 0} reference planes
+template <bool PN, int kU, bool PK, bool OTF = false>  // PK: packed {img, dx, dy, 0} reference planes; OTF: image plane only
 __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartHStride];
@@ -671,6 +720,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
   gconst_f32 pref = (gconst_f32)pl.ref, pdx = (gconst_f32)pl.dx, pdy = (gconst_f32)pl.dy;
   gconst_f32x4 ppack = (gconst_f32x4)pl.pack;
   const int sw = lc.sw;
+  const int wl = (int)lc.swo, hl = (int)lc.sho, padl = (sw - wl) / 2;  // (OTF) the level's unpadded size, its padding
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -704,6 +754,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
     const int base_v = tp.row0 * sw + tp.col0;
     const int vis_v = vis ? 1 : 0;
+    const int tx_v = tp.col0 - padl, ty_v = tp.row0 - padl;  // (OTF) tap a of pixel (0,0) in unpadded image coordinates
     {
       float4 *r4 = reinterpret_cast<float4 *>(rec + lane * kRec);
       r4[0] = make_float4(tp.w0, tp.w1, tp.w2, tp.w3);
@@ -727,7 +778,12 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         const int base = rlane(base_v, jj);
         L.vis[u] = rlane(vis_v, jj);
         if (L.vis[u]) {  // wave-uniform
-          if constexpr (PK) {
+          if constexpr (OTF) {
+            L.tx[u] = rlane(tx_v, jj);
+            L.ty[u] = rlane(ty_v, jj);
+            L.inner[u] = (L.tx[u] >= 2 && L.tx[u] + 7 <= wl - 2 && L.ty[u] >= 2 && L.ty[u] + 7 <= hl - 2) ? 1 : 0;
+            L.o[u] = taps_issue_otf(pref + base, loff, sw);
+          } else if constexpr (PK) {
             L.p4[u] = taps_issue4(ppack + base, loff, sw, lane);
           } else {
             L.r[u] = taps_issue(pref + base, loff, sw, lane);
@@ -752,7 +808,10 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         {
           const float4 w = rec4[L.rec[u] * 4 + 0];
           float t;
-          if constexpr (PK) {
+          if constexpr (OTF) {
+            taps_blend_otf(L.o[u], w.x, w.y, w.z, w.w, L.inner[u] != 0, L.tx[u] + (lane & 7), L.ty[u] + (lane >> 3), wl, hl,
+                           t, gx, gy);
+          } else if constexpr (PK) {
             t = taps_blend4(L.p4[u], 0, w.x, w.y, w.z, w.w, lane);
             gx = taps_blend4(L.p4[u], 1, w.x, w.y, w.z, w.w, lane);
             gy = taps_blend4(L.p4[u], 2, w.x, w.y, w.z, w.w, lane);
@@ -1515,9 +1574,17 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
     nblk = gridx8;
     const dim3 g8(gridx8, e.B);
     const bool pk = e.packed && !(variant & 4096);  // variant bit 12: three separate planes (A/B)
+    // gradients on the fly from the image plane whenever the reference pyramids are builder-made (r03: 287 -> 242 us per
+    // level-0 launch of 32 pairs; a must for image-only pyramids, e.otf == 2); variant bit 27 (134217728): read the
+    // gradient planes instead (A/B, cross-check)
+    const bool otf = e.otf == 2 || (e.otf == 1 && !(variant & (1 << 27)));
     // patches per pipeline step: two with the packed planes (measured r02: 1 -> 2 saves 50-120 us per level, 4 adds
     // nothing), one otherwise
-    if (pk && e.dopatchnorm)
+    if (otf && e.dopatchnorm)
+      hipLaunchKernelGGL((k_ref8<true, 1, false, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (otf)
+      hipLaunchKernelGGL((k_ref8<false, 2, false, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (pk && e.dopatchnorm)
       hipLaunchKernelGGL((k_ref8<true, 1, true>), g8, blk, 0, s, e, lc, level, cpw);
     else if (pk)
       hipLaunchKernelGGL((k_ref8<false, 2, true>), g8, blk, 0, s, e, lc, level, cpw);

@@ -107,3 +107,53 @@ def test_get_patch_bit_exact_incl_borders(oracle, psz, dpn):
     with pytest.raises(IctrError):
         ic.util_getPatch(g, 0, np.array([[w + 1.0, 5.0]], np.float32), op)  # outside the image: refused, not read
     assert ic.util_getPatch(g, 0, np.zeros((0, 2), np.float32), op).shape == (0, psz * psz)
+
+
+@pytest.mark.parametrize("n,margin", [(700, 0.5), (9000, 0.5)])
+def test_gradients_on_the_fly_give_the_planes_bits(n, margin):
+    """the 8x8 setup kernel forms Gx / Gy from the IMAGE plane (I(x+1) - I(x-1) with the builder's
+    reflect-101 / zero-padding rules, utilities.cpp:30-45) instead of reading the dx / dy / packed planes. Same
+    subtraction, same blend: T, Gx, Gy, the coefficients and the poses must be the planes' bit for bit -- points right
+    at the image border included (margin 0.5 px) -- (a) on an ordinary pyramid against variant bit 27 (which reads the planes), (b) with a reference
+    pyramid that holds nothing but the image levels (getgrad = 2). 700 points: per-iteration launches (variant bit 13);
+    9000 points: the resident-iteration form."""
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(640, 384, n_points=n, seed=21, margin=margin)
+    op = ic.optparam(2, 0, 8, 4, 0.0, 0, 0, n)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    pa_img = ic.Pyramid(sc["img_a"], 2, 8, getgrad=2)
+    base = 8192 if n < 8193 else 0
+    res = []
+    for variant, ref in ((base | (1 << 27), pa), (base, pa), (base, pa_img)):
+        e = ic.TrackBatch(cam, op, 1)
+        e.set_variant(variant)
+        e.Set3Dpoints(0, sc["pts3d"].copy())
+        e.SetPose(0, sc["p_a"], ref, pb)
+        e.track_async()
+        p = e.poses()
+        res.append((p, e.read_buffer(0, 0, 64 * n), e.read_buffer(0, 1, 64 * n), e.read_buffer(0, 2, 64 * n),
+                    e.read_buffer(0, 7, 16 * n), e.path_name()))
+    assert ("k_level_resident" in res[0][5]) == (n >= 8193)
+    for k in (1, 2):
+        for q in range(5):
+            assert np.array_equal(res[0][q], res[k][q]), (k, q, np.abs(res[0][q] - res[k][q]).max())
+    assert np.abs(res[0][1]).max() > 1 and np.abs(res[0][2]).max() > 0.1
+    # border patches were really among them: some patch has an exactly-zero gradient column / row next to non-zero ones
+    gx = res[0][2].reshape(n, 8, 8)
+    assert np.any((np.abs(gx).sum(axis=(1, 2)) > 0) & (np.abs(gx).min(axis=(1, 2)) == 0))
+
+
+def test_image_only_pyramid_is_refused_where_no_kernel_forms_gradients():
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(320, 256, n_points=60, seed=3)
+    op = ic.optparam(2, 0, 8, 3, 0.0, 0, 0, 60)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa_img, pb = ic.Pyramid(sc["img_a"], 2, 8, getgrad=2), ic.Pyramid(sc["img_b"], 2, 8, getgrad=0)
+    e = ic.TrackBatch(cam, op, 1)
+    e.Set3Dpoints(0, sc["pts3d"].copy())
+    e.SetPose(0, sc["p_a"], pa_img, pb)
+    with pytest.raises(ic.IctrError, match="on the fly"):     # 60 points: the one-launch tracker reads the planes
+        e.track_async()
+    with pytest.raises(ic.IctrError, match="gradient"):
+        ic.util_getPatch_grad(pa_img, 0, np.array([[20.0, 20.0]], np.float32), op)
