@@ -703,13 +703,32 @@ def main():
                         "duration_basis": "HIP events on the engine's stream around each k_level_resident launch of the timed "
                                           "steps (nothing overlaps: one engine, one stream)",
                         "note": "algorithmic bytes = SURVEY.md 8d's 16 B per patch pixel and iteration x maxiter x the launch's "
-                                "pixels. This kernel does NOT move them: T / Gx / Gy are loaded once per level and stay on "
-                                "the chip, an iteration reads only the cache-resident current frame -- `traffic` is what "
-                                "crosses HBM. `achieved` is therefore an equivalent rate and can exceed the HBM peak; the "
-                                "kernel is bound by its per-iteration latency chain (two mailbox hops + solve), not by "
-                                "bandwidth. The streaming kernel's own figure is roofline.streaming_kernel.",
+                                "pixels (the contract's figure). This kernel does NOT move them -- T / Gx / Gy cross HBM once "
+                                "per level and stay on the chip, an iteration reads only the current frame's windows -- so "
+                                "`achieved` is an equivalent rate, exceeds the HBM peak, and says how far the form is past "
+                                "the streaming formulation's roofline, not how close it is to its own bound. Its own "
+                                "bounds are in `resident_bounds`: the bytes it must move (a small fraction of HBM time) and "
+                                "the per-iteration dependency chain that actually sets its pace.",
                         "per_level_launch_us": [float(x) / (args.steps * n_eng_step) * 1e3 for x in ev_iters],
                         "us_per_iteration_equivalent": t_launch * 1e6 / args.maxiter}
+                # what bounds THIS kernel. (1) HBM floor: T, Gx, Gy once per level (12 B per patch pixel) + every distinct
+                # current-frame texel once (4 B / 4^level per patch pixel). (2) The chain: a pair's iterations are serial,
+                # pairs_in_flight (the chip holds four 1080p pairs' templates) overlap: launch >= rounds x maxiter x
+                # chain; chain = profiles/r03_notes.md's stamped phases of one iteration with the pair alone on the chip.
+                min_bytes = float(np.mean([(12.0 + 4.0 / 4.0 ** l) * pix_per_iter * pairs_per_launch for l in range(args.levels)]))
+                in_flight = 4
+                chain_us = 8.2
+                rounds = -(-pairs_per_launch // in_flight)
+                roof["resident_bounds"] = {
+                    "hbm_floor_bytes_per_launch": min_bytes, "hbm_floor_us": min_bytes / 8e12 * 1e6,
+                    "hbm_floor_frac": min_bytes / 8e12 / t_launch,
+                    "pairs_in_flight": in_flight, "chain_us_per_iteration_alone": chain_us,
+                    "chain_floor_us_per_launch": rounds * args.maxiter * chain_us,
+                    "chain_floor_frac": rounds * args.maxiter * chain_us * 1e-6 / t_launch,
+                    "basis": "hbm floor: (12 + 4 / 4^level) B per patch pixel, mean over the levels, at 8 TB/s; chain floor: "
+                             "ceil(pairs / 4 in flight) x maxiter x 8.2 us (stage 1 + 2 of one wave 3.5, wave reduction 0.4, "
+                             "gather hop incl. the skew of 254 workgroups 2.2, solver turn 1.4, broadcast hop 0.9; "
+                             "tools/restrace.py, profiles/r03_notes.md), template prologues not counted"}
                 # the streaming form beside it (the kernel every other configuration runs: sharded multi-GPU mode, small
                 # patch sizes, robustness options): one 16-pair engine with variant bit 21, its launches alone
                 try:

@@ -349,28 +349,38 @@ def rec_pyramid(seconds):
     rng = np.random.default_rng(3)
     frame = torch.from_numpy(rng.integers(0, 256, (h, w)).astype(np.float32)).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    pyr = ic.Pyramid(lv_f=lv_f, imgpadding=pad, device_ptr=frame.data_ptr(), wh=(w, h), stream=st)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    times = []
+    res = {}
+    for gg in (1, 2):  # 1: image + dx + dy + packed texels (the reference's getgrad); 2: image levels only (r03)
+        pyr = ic.Pyramid(lv_f=lv_f, imgpadding=pad, device_ptr=frame.data_ptr(), wh=(w, h), stream=st, getgrad=gg)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
 
-    def step():  # K frames back to back (torch's current stream is the stream the kernels are launched on)
-        ev0.record()
-        for _ in range(K):
-            pyr.rebuild(device_ptr=frame.data_ptr(), stream=st)
-        ev1.record()
-        ev1.synchronize()
-        times.append(ev0.elapsed_time(ev1) * 1e-3 / K)
+        def step():  # K frames back to back (torch's current stream is the stream the kernels are launched on)
+            ev0.record()
+            for _ in range(K):
+                pyr.rebuild(device_ptr=frame.data_ptr(), stream=st)
+            ev1.record()
+            ev1.synchronize()
+            times.append(ev0.elapsed_time(ev1) * 1e-3 / K)
 
-    _budget_loop(step, seconds)
-    t = float(np.median(times[1:] or times))
+        _budget_loop(step, seconds / 2)
+        px_out = sum(pyr.level_dims(l)[0] * pyr.level_dims(l)[1] for l in range(lv_f + 1))
+        res[gg] = (float(np.median(times[1:] or times)), len(times), px_out)
+        del pyr
+    t, reps, px_out = res[1]
+    t2 = res[2][0]
     px_in = sum((w >> l) * (h >> l) for l in range(lv_f + 1))
-    px_out = sum(pyr.level_dims(l)[0] * pyr.level_dims(l)[1] for l in range(lv_f + 1))
     alg = 4.0 * px_in + 28.0 * px_out  # read every level's source once; write image, dx, dy and the 16-B packed texel
+    alg2 = 4.0 * px_in + 4.0 * px_out
     return {"name": "pyramid", "workload": f"util_constructpyramide of one {w}x{h} frame (device-resident f32), {lv_f + 1} "
             f"levels, padding {pad}, gradients + packed texels, refilled in place ({K} frames back to back per sample)",
-            "value": 1.0 / t, "unit": "frames/s", "ms_per_step": t * 1e3, "reps": len(times), "kernel": "k_pyr_level "
+            "value": 1.0 / t, "unit": "frames/s", "ms_per_step": t * 1e3, "reps": reps, "kernel": "k_pyr_level "
             "(one launch per level)", "kernel_us": t * 1e6, "algorithmic_bytes_per_launch": alg,
             "achieved_GBps": alg / t / 1e9, "frac": alg / t / 1e9 / PEAK,
+            "image_only": {"what": "getgrad = 2: image levels only, the tracker's 8x8 setup kernel forms the gradient patches "
+                                   "on the fly (bit-identical patches, tests/test_gpu_pyramid_patch.py)",
+                           "kernel_us": t2 * 1e6, "speedup": t / t2, "algorithmic_bytes_per_launch": alg2,
+                           "frac": alg2 / t2 / 1e9 / PEAK, "note": "three dependent ~4 us launches: launch-bound"},
             "note": "three dependent launches per frame; bit-exact against the oracle (tests/test_gpu_pyramid_patch.py)"}
 
 
