@@ -280,8 +280,11 @@ int ictr_batch_get_first_iter_times(ictr_batch *b, float *ms_first);
 int ictr_timebase_mark(void);
 int ictr_batch_get_kernel_intervals(ictr_batch *b, float *start_ms, float *end_ms);
 int ictr_batch_get_setup_intervals(ictr_batch *b, float *start_ms, float *end_ms); /* [level]: the setup launches */
-/* which launch form the last tracking used: 0 = per-iteration launches (large problems), 1 = the one-launch tracker
- * (whole odometer.cpp:257-426 loop in one kernel, one workgroup per problem; chosen for small problems) */
+/* which launch form the last tracking used: 0 = per-iteration launches (plain), 1 = the one-launch tracker (whole
+ * odometer.cpp:257-426 loop in one kernel; one workgroup or a team of workgroups per problem, see ictr_batch_last_team),
+ * 2 = per-iteration launches replayed as one hipGraph, 3 = the one-launch tracker with the begin phase and the state
+ * read-back inside the launch, 4 = the resident-iteration form (one setup launch + one k_level_resident launch per
+ * level: dense problems of >= 8193 8x8 patches) */
 int ictr_batch_last_path(const ictr_batch *b);
 /* workgroups per problem of that launch when it was the one-launch tracker (1 otherwise): problems of a few hundred to a
  * few thousand 8x8 patches are shared by a team of workgroups that all-gather their partial sums inside the launch */
