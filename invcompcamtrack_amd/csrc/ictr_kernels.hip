@@ -702,8 +702,12 @@ struct RefLoads {
   int tx[kU], ty[kU];  // OTF: unpadded coordinates of tap a of pixel (0, 0)
 };
 
-template <bool PN, int kU, bool PK, bool OTF = false>  // PK: packed {img, dx, dy, 0} reference planes; OTF: image plane only
+// ST (with OTF, without PN): the chunk's patches in statically unrolled groups of SIXTEEN -- three windows in flight,
+// and the three sums of S per patch by the transposing wave reduction of the resident kernel (TrAcc, ictr_devfn.h: ~10
+// instructions per patch instead of the 42 of three wave sums + selects); everything else as in the dynamic form.
+template <bool PN, int kU, bool PK, bool OTF = false, bool ST = false>  // PK: packed {img, dx, dy, 0} planes; OTF: image plane only
 __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int level, int cpw) {
+  static_assert(!ST || (OTF && !PN), "the static form exists for on-the-fly gradients without patch normalisation");
   __shared__ __attribute__((aligned(16))) float sRec[kWaves][64 * kRec];
   __shared__ float sW[kWaves][kPartHStride];
   const int b = blockIdx.y;
@@ -830,6 +834,45 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         patch_sums(gx, gy, L.rec[u]);
       }
     };
+    if constexpr (ST) {
+      const int inner_v = (tx_v >= 2 && tx_v + 7 <= wl - 2 && ty_v >= 2 && ty_v + 7 <= hl - 2) ? 1 : 0;
+      for (int g0 = 0; g0 < cnt; g0 += 16) {  // (wave-uniform trip count: cnt is)
+        const unsigned vmask = (unsigned)(__builtin_amdgcn_ballot_w64(vis) >> g0) & 0xffffu;  // the group's visible points
+        TapLoadsOTF W3[3];
+        auto issue_s = [&](int j) {
+          if ((vmask >> j) & 1u) W3[j % 3] = taps_issue_otf(pref + rlane(base_v, g0 + j), loff, sw);
+        };
+        issue_s(0);
+        issue_s(1);
+        issue_s(2);
+        TrAcc<16> accS, accX;
+        tr_for_each_patch<16, 0>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          float gx = 0.0f, gy = 0.0f;
+          if ((vmask >> j) & 1u) {  // wave-uniform
+            const float4 w = rec4[(g0 + j) * 4 + 0];
+            float t;
+            taps_blend_otf(W3[j % 3], w.x, w.y, w.z, w.w, rlane(inner_v, g0 + j) != 0, rlane(tx_v, g0 + j) + (lane & 7),
+                           rlane(ty_v, g0 + j) + (lane >> 3), wl, hl, t, gx, gy);
+            const size_t po = (size_t)(i0 + g0 + j) * 64;
+            __builtin_nontemporal_store(t, T + po + lane);
+            __builtin_nontemporal_store(gx, Gx + po + lane);
+            __builtin_nontemporal_store(gy, Gy + po + lane);
+          }
+          if constexpr (j + 3 < 16) issue_s(j + 3);
+          accS.template push<j>(gx * gx, gy * gy, lane);
+          accX.template push<j>(gx * gy, 0.0f, lane);
+        });
+        // lane = point again: the group's sixteen points are the lanes g0 .. g0 + 15
+        const int pp = lane & 15;
+        const float sxx = lane_gather(accS.F, tr_lane_of<16>(pp, 0)), syy = lane_gather(accS.F, tr_lane_of<16>(pp, 1));
+        const float sxy = lane_gather(accX.F, tr_lane_of<16>(pp, 0));
+        const bool mine = (lane >> 4) == (g0 >> 4);
+        sxx_v = mine ? sxx : sxx_v;
+        sxy_v = mine ? sxy : sxy_v;
+        syy_v = mine ? syy : syy_v;
+      }
+    } else {
     RefLoads<kU> A, B;
     issue(A, 0);
     for (int sidx = 0; sidx < nsteps; sidx += 2) {
@@ -837,6 +880,7 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
       reduce(A);
       if (sidx + 2 < nsteps) issue(A, sidx + 2);
       if (sidx + 1 < nsteps) reduce(B);
+    }
     }
     // points out of the reference view at this level (rare): S of the stale patch, from the stored gradients
     for (unsigned long long stale = __builtin_amdgcn_ballot_w64(pv && !vis); stale; stale &= stale - 1) {
@@ -1582,6 +1626,8 @@ void launch_ref_level(const EngineDev &e, const LevelCam &lc, int level, int gri
     // nothing), one otherwise
     if (otf && e.dopatchnorm)
       hipLaunchKernelGGL((k_ref8<true, 1, false, true>), g8, blk, 0, s, e, lc, level, cpw);
+    else if (otf && cpw % 16 == 0 && !(variant & (1 << 28)))  // variant bit 28 (268435456): the dynamic patch loop (A/B)
+      hipLaunchKernelGGL((k_ref8<false, 2, false, true, true>), g8, blk, 0, s, e, lc, level, cpw);
     else if (otf)
       hipLaunchKernelGGL((k_ref8<false, 2, false, true>), g8, blk, 0, s, e, lc, level, cpw);
     else if (pk && e.dopatchnorm)

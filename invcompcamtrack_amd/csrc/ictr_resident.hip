@@ -135,110 +135,7 @@ __device__ __forceinline__ unsigned long long res_poll1(ResPoll &pc, const unsig
   return g;
 }
 
-// ---------------------------------------------------------------- transposing wave reduction
-// merge(u, v) on lane bit k: the lanes with bit k = 0 end up with u summed over the lane pair {l, l ^ (1 << k)}, the
-// lanes with bit k = 1 with v summed over the same pair. Six levels of merges (one per lane bit) take 64 per-lane
-// values to ONE register in which every lane holds the complete 64-lane sum of one of the values.
-//   bits 2, 3: two DPP adds, each writing half of the banks (row_shl / row_shr by 4 or 8 with a bank mask);
-//   bits 4, 5: v_permlane16_swap / v_permlane32_swap (gfx950) + one add;  bits 0, 1: quad permutes + select.
-// (inline DPP: the s_nop covers the "VALU write -> DPP read" hazard, which the compiler cannot see inside asm)
-__device__ __forceinline__ float tr_merge_b2(float u, float v) {
-  float w;
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "=v"(w) : "v"(u));
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(w) : "v"(v));
-  return w;
-}
-__device__ __forceinline__ float tr_merge_b3(float u, float v) {
-  float w;
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3" : "=v"(w) : "v"(u));
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(w) : "v"(v));
-  return w;
-}
-// (inline asm: with ROCm 7.2's hipcc the two results of __builtin_amdgcn_permlane16/32_swap come back as the SAME register
-// -- "v_permlane16_swap v25, v26; v_add_f32 v6, v25, v25" -- found by tests/test_gpu_parity.py's reduction test; the
-// s_nops cover the VALU-write -> permlane-swap hazard on both sides, which the compiler cannot see inside asm)
-__device__ __forceinline__ float tr_merge_b4(float u, float v) {  // rows (16 lanes): [u0 u1 u2 u3],[v0..] -> [u0+u1, v0+v1, u2+u3, v2+v3]
-  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(u), "+v"(v));  // odd rows of u <-> even rows of v
-  return u + v;
-}
-__device__ __forceinline__ float tr_merge_b5(float u, float v) {  // halves: -> [u_lo + u_hi, v_lo + v_hi]
-  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(u), "+v"(v));  // upper half of u <-> lower half of v
-  return u + v;
-}
-__device__ __forceinline__ float tr_merge_b0(float u, float v, int lane) {
-  const float t = u + dpp_mov<0xB1>(u), s = v + dpp_mov<0xB1>(v);
-  return (lane & 1) ? s : t;
-}
-__device__ __forceinline__ float tr_merge_b1(float u, float v, int lane) {
-  const float t = u + dpp_mov<0x4E>(u), s = v + dpp_mov<0x4E>(v);
-  return (lane & 2) ? s : t;
-}
-// level L = 1..5 of the reduction tree over a wave's 32 patches (level 0 = the patch's own (A, B) pair on lane bit 2)
-template <int L>
-__device__ __forceinline__ float tr_merge_level(float u, float v, int lane) {
-  if constexpr (L == 1) return tr_merge_b3(u, v);
-  if constexpr (L == 2) return tr_merge_b4(u, v);
-  if constexpr (L == 3) return tr_merge_b5(u, v);
-  if constexpr (L == 4) return tr_merge_b0(u, v, lane);
-  return tr_merge_b1(u, v, lane);
-}
-// which patch of the wave and which of its two sums (0: A = sum Gx r, 1: B = sum Gy r) lane l holds at the end. NP = 32:
-// all six lane bits are consumed by merges; NP = 16: the last bit (1) is summed plainly, so lane pairs {l, l ^ 2} hold the
-// same sum and only the lanes with bit 1 clear ("primary") may contribute it
-template <int NP>
-__device__ __forceinline__ int tr_patch_of_lane(int l) {
-  const int p = ((l >> 3) & 1) | (((l >> 4) & 1) << 1) | (((l >> 5) & 1) << 2) | ((l & 1) << 3);
-  return NP == 32 ? (p | (((l >> 1) & 1) << 4)) : p;
-}
-__device__ __forceinline__ int tr_kind_of_lane(int l) { return (l >> 2) & 1; }
-template <int NP>
-__device__ __forceinline__ bool tr_primary_lane(int l) { return NP == 32 ? true : ((l & 2) == 0); }
-// the binary counter of pending registers: push<J>(A, B) takes patch J's pair of per-lane values (J = 0..NP-1 in order);
-// after push<NP-1> `F` holds, in lane l, the 64-lane sum of (A if kind == 0 else B) of patch tr_patch_of_lane<NP>(l)
-template <int NP>
-struct TrAcc {
-  static_assert(NP == 32 || NP == 16, "patches per wave");
-  float p1, p2, p3, p4, p5, F;
-  template <int J>
-  __device__ __forceinline__ void push(float A, float B, int lane) {
-    float m = tr_merge_b2(A, B);
-    if constexpr ((J & 1) == 0) {
-      p1 = m;
-    } else {
-      m = tr_merge_level<1>(p1, m, lane);
-      if constexpr ((J & 2) == 0) {
-        p2 = m;
-      } else {
-        m = tr_merge_level<2>(p2, m, lane);
-        if constexpr ((J & 4) == 0) {
-          p3 = m;
-        } else {
-          m = tr_merge_level<3>(p3, m, lane);
-          if constexpr ((J & 8) == 0) {
-            p4 = m;
-          } else {
-            m = tr_merge_level<4>(p4, m, lane);
-            if constexpr (NP == 16) {
-              F = m + dpp_mov<0x4E>(m);  // lane bit 1: plain sum
-            } else if constexpr ((J & 16) == 0) {
-              p5 = m;
-            } else {
-              F = tr_merge_level<5>(p5, m, lane);
-            }
-          }
-        }
-      }
-    }
-  }
-};
-template <int NP, int J, class Fn>
-__device__ __forceinline__ void tr_for_each_patch(Fn &&fn) {  // fn(integral_constant<J>) for J = 0..NP-1, in order
-  if constexpr (J < NP) {
-    fn(std::integral_constant<int, J>{});
-    tr_for_each_patch<NP, J + 1>(fn);
-  }
-}
-
+// (the transposing wave reduction -- tr_merge_*, TrAcc, tr_for_each_patch -- lives in ictr_devfn.h: k_ref8 uses it too)
 // inspection (tests/test_gpu_parity.py): the reduction alone on caller data, vals[lane][2 patch + kind]
 template <int NP>
 __global__ __launch_bounds__(64) void k_debug_transpose_reduce(const float *__restrict__ vals, float *__restrict__ out,
@@ -321,13 +218,6 @@ __device__ __forceinline__ void res_issue_range(Fn &&fn) {  // fn(k) for k = FRO
     res_issue_range<FROM + 1, TO>(fn);
   }
 }
-// inverse of tr_patch_of_lane / tr_kind_of_lane: the (primary) lane that holds sum `kind` of patch p
-template <int NP>
-__device__ __forceinline__ int tr_lane_of(int p, int kind) {
-  return ((p >> 3) & 1) | ((NP == 32 ? ((p >> 4) & 1) : 0) << 1) | (kind << 2) | ((p & 1) << 3) | (((p >> 1) & 1) << 4) |
-         (((p >> 2) & 1) << 5);
-}
-
 // FUSED: the level's setup (steps 4-6: odometer.cpp:268-334, 428-472) happens in the pair's prologue -- every wave
 // gathers and blends the reference patches of its own points straight into the registers / LDS they stay in, sums
 // S = (sum Gx^2, sum Gx Gy, sum Gy^2) per patch and posts the workgroup's part of H = sum J^T S J to the pair's solver

@@ -109,15 +109,19 @@ def test_get_patch_bit_exact_incl_borders(oracle, psz, dpn):
     assert ic.util_getPatch(g, 0, np.zeros((0, 2), np.float32), op).shape == (0, psz * psz)
 
 
-@pytest.mark.parametrize("n,margin", [(700, 0.5), (9000, 0.5)])
-def test_gradients_on_the_fly_give_the_planes_bits(n, margin):
+@pytest.mark.parametrize("n,margin,cpw", [(700, 0.5, 0), (9000, 0.5, 0), (700, 0.5, 16), (9000, 0.5, 32), (2500, 0.5, 64)])
+def test_gradients_on_the_fly_give_the_planes_bits(n, margin, cpw, monkeypatch):
     """the 8x8 setup kernel forms Gx / Gy from the IMAGE plane (I(x+1) - I(x-1) with the builder's
     reflect-101 / zero-padding rules, utilities.cpp:30-45) instead of reading the dx / dy / packed planes. Same
     subtraction, same blend: T, Gx, Gy, the coefficients and the poses must be the planes' bit for bit -- points right
     at the image border included (margin 0.5 px) -- (a) on an ordinary pyramid against variant bit 27 (which reads the planes), (b) with a reference
     pyramid that holds nothing but the image levels (getgrad = 2). 700 points: per-iteration launches (variant bit 13);
-    9000 points: the resident-iteration form."""
+    9000 points: the resident-iteration form. cpw (points per wave chunk, ICTR_CPW) 16 / 32 / 64: the statically
+    unrolled 16-patch groups of k_ref8 with the transposing reduction for S (what large batches run); 0: the chunk size
+    the host picks for this problem (small: the dynamic patch loop)."""
     from invcompcamtrack_amd import synth
+    if cpw:
+        monkeypatch.setenv("ICTR_CPW", str(cpw))
     sc = synth.make_scene(640, 384, n_points=n, seed=21, margin=margin)
     op = ic.optparam(2, 0, 8, 4, 0.0, 0, 0, n)
     cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
@@ -136,8 +140,11 @@ def test_gradients_on_the_fly_give_the_planes_bits(n, margin):
                     e.read_buffer(0, 7, 16 * n), e.path_name()))
     assert ("k_level_resident" in res[0][5]) == (n >= 8193)
     for k in (1, 2):
-        for q in range(5):
+        for q in range(1, 5):   # T, Gx, Gy, coefficients: bit for bit
             assert np.array_equal(res[0][q], res[k][q]), (k, q, np.abs(res[0][q] - res[k][q]).max())
+        # poses: H is summed in another order by the static form (transposing reduction), nothing else differs
+        assert np.abs(res[0][0] - res[k][0]).max() <= (0.0 if cpw == 0 else 2e-6), np.abs(res[0][0] - res[k][0]).max()
+    assert np.array_equal(res[1][0], res[2][0])   # planes or no planes in the pyramid: the same kernel, the same bits
     assert np.abs(res[0][1]).max() > 1 and np.abs(res[0][2]).max() > 0.1
     # border patches were really among them: some patch has an exactly-zero gradient column / row next to non-zero ones
     gx = res[0][2].reshape(n, 8, 8)
