@@ -691,6 +691,14 @@ __device__ __forceinline__ void taps_blend_otf(const TapLoadsOTF &t, float w0, f
   gy = w0 * ya + w1 * yb + w2 * yc + w3 * yd;
 }
 
+template <int I, int N, class Fn>
+__device__ __forceinline__ void res_static_for(Fn &&fn) {  // fn(integral_constant<I>) ... fn(integral_constant<N - 1>)
+  if constexpr (I < N) {
+    fn(std::integral_constant<int, I>{});
+    res_static_for<I + 1, N>(fn);
+  }
+}
+
 template <int kU>
 struct RefLoads {
   TapLoads r[kU], x[kU], y[kU];
@@ -838,13 +846,15 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
       const int inner_v = (tx_v >= 2 && tx_v + 7 <= wl - 2 && ty_v >= 2 && ty_v + 7 <= hl - 2) ? 1 : 0;
       for (int g0 = 0; g0 < cnt; g0 += 16) {  // (wave-uniform trip count: cnt is)
         const unsigned vmask = (unsigned)(__builtin_amdgcn_ballot_w64(vis) >> g0) & 0xffffu;  // the group's visible points
-        TapLoadsOTF W3[3];
+#ifndef ICTR_REF8_D
+#define ICTR_REF8_D 3  // windows in flight per wave (12 registers each)
+#endif
+        constexpr int kD = ICTR_REF8_D;
+        TapLoadsOTF W3[kD];
         auto issue_s = [&](int j) {
-          if ((vmask >> j) & 1u) W3[j % 3] = taps_issue_otf(pref + rlane(base_v, g0 + j), loff, sw);
+          if ((vmask >> j) & 1u) W3[j % kD] = taps_issue_otf(pref + rlane(base_v, g0 + j), loff, sw);
         };
-        issue_s(0);
-        issue_s(1);
-        issue_s(2);
+        res_static_for<0, kD>([&](auto jc) { issue_s(decltype(jc)::value); });
         TrAcc<16> accS, accX;
         tr_for_each_patch<16, 0>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
@@ -852,14 +862,14 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
           if ((vmask >> j) & 1u) {  // wave-uniform
             const float4 w = rec4[(g0 + j) * 4 + 0];
             float t;
-            taps_blend_otf(W3[j % 3], w.x, w.y, w.z, w.w, rlane(inner_v, g0 + j) != 0, rlane(tx_v, g0 + j) + (lane & 7),
+            taps_blend_otf(W3[j % kD], w.x, w.y, w.z, w.w, rlane(inner_v, g0 + j) != 0, rlane(tx_v, g0 + j) + (lane & 7),
                            rlane(ty_v, g0 + j) + (lane >> 3), wl, hl, t, gx, gy);
             const size_t po = (size_t)(i0 + g0 + j) * 64;
             __builtin_nontemporal_store(t, T + po + lane);
             __builtin_nontemporal_store(gx, Gx + po + lane);
             __builtin_nontemporal_store(gy, Gy + po + lane);
           }
-          if constexpr (j + 3 < 16) issue_s(j + 3);
+          if constexpr (j + kD < 16) issue_s(j + kD);
           accS.template push<j>(gx * gx, gy * gy, lane);
           accX.template push<j>(gx * gy, 0.0f, lane);
         });
