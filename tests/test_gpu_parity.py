@@ -923,3 +923,53 @@ def test_maxiter_zero_and_timing_getters(oracle):
     b2.poses()
     tot, first = b2.kernel_times(), b2.first_iter_times()
     assert np.all(first > 0) and np.all(tot > first)
+
+
+def test_two_host_threads_drive_spin_waiting_launches_at_once(oracle):
+    """admission of the in-launch-synchronised forms used to be check-then-act -- two host threads (ctypes
+    releases the GIL) could both pass the budget test before either launch was visible, oversubscribe the CUs and run
+    every poll into its time-out. Admit + launch + record is one critical section per device now: a resident-form engine
+    (two pairs of 9000 points: 2 x 72 workgroups) and a team-form engine (eight problems x 63 workgroups) tracked from two
+    threads at once, ten times, give their single-thread poses bit for bit and no time-out."""
+    import threading
+    torch = pytest.importorskip("torch")
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(640, 384, n_points=9000, seed=3)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    res = ic.TrackBatch(cam, ic.optparam(2, 0, 8, 5, 0.0, 0, 0, 9000), 2)
+    team = ic.TrackBatch(cam, ic.optparam(2, 0, 8, 5, 0.0, 0, 0, 2500), 8)
+    team.set_team(40, 0, 1 << 30)
+    for k in range(2):
+        res.Set3Dpoints(k, sc["pts3d"].copy())
+    for k in range(8):
+        team.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :2500]))
+    P2, P8 = np.tile(sc["p_a"], (2, 1)), np.tile(sc["p_a"], (8, 1))
+
+    def run(e, P, n, out, errs):
+        try:
+            for _ in range(n):
+                e.SetPoseAll(P, pa, pb)
+                e.track_async()
+                out.append(e.poses().copy())
+        except Exception as exc:   # an exchange time-out surfaces here
+            errs.append(exc)
+
+    ref_r, ref_t, errs = [], [], []
+    run(res, P2, 1, ref_r, errs)
+    run(team, P8, 1, ref_t, errs)
+    assert not errs and "k_level_resident" in res.path_name() and team.last_team() > 1
+    res.set_stream(s1.cuda_stream)
+    team.set_stream(s2.cuda_stream)
+    out_r, out_t = [], []
+    th = [threading.Thread(target=run, args=(res, P2, 10, out_r, errs)),
+          threading.Thread(target=run, args=(team, P8, 10, out_t, errs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert len(out_r) == 10 and len(out_t) == 10
+    assert all(np.array_equal(p, ref_r[0]) for p in out_r) and all(np.array_equal(p, ref_t[0]) for p in out_t)
