@@ -333,6 +333,16 @@ int ictr_p2p_connect(ictr_p2p *p, const void *all_handles);        /* world hand
 int ictr_p2p_allreduce(ictr_p2p *p, float *dev_buf, int64_t count, void *hip_stream); /* in place, asynchronous */
 int ictr_p2p_error(ictr_p2p *p); /* 1 if an exchange timed out (a peer never arrived); synchronises the device */
 void ictr_p2p_destroy(ictr_p2p *p);
+/* Sharded RESIDENT form (r03): the batch holds this rank's shard of every problem's points, and its resident-iteration
+ * launches (one per level, all iterations inside) add H -- once per level -- and b -- once per iteration -- over the ranks
+ * THEMSELVES: a frame pair's solver workgroup writes its sums into every rank's mailbox and polls its own (the protocol
+ * above, inside the launch: no kernel boundary, no host call, no communicator between two iterations). p: a connected
+ * ictr_p2p with count >= 64 * nproblems, created alike on every rank; NULL switches the exchange off again. Every rank
+ * must run the same trackings (same problems, levels, iteration limits); their loop decisions stay in lockstep because
+ * every rank solves on identical sums. A tracking that cannot run in the resident form (see ictr_odometer_set_variant)
+ * fails with ICTR_ERR_STATE instead of running unsynchronised; a peer that never arrives ends the launch after
+ * ICTR_TEAM_TIMEOUT_S and the wait returns ICTR_ERR_HIP. */
+int ictr_batch_set_peer_exchange(ictr_batch *b, ictr_p2p *p);
 
 /* ------------------------------------------------------------------ flow producer for the misc_src/run_*OF* drivers
  * Those drivers shell out to an external optical-flow binary that is not in the reference repository

@@ -147,6 +147,7 @@ SIGNATURES = {
     "ictr_p2p_allreduce": (C.c_int, [VP, VP, I64, VP]),
     "ictr_p2p_error": (C.c_int, [VP]),
     "ictr_p2p_destroy": (None, [VP]),
+    "ictr_batch_set_peer_exchange": (C.c_int, [VP, VP]),
     "ictr_patchflow": (C.c_int, [VP, VP, FP, I64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, FP, IP, IP]),
     "ictr_patchflow_last_kernel_ms": (C.c_float, []),
     "ictr_icgn_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, IP,

@@ -59,6 +59,18 @@ struct T1Team {
   int mute;                  // debug (variant bit 25): part `mute - 1` never posts its values (time-out test); 0 = off
 };
 
+// Cross-GPU exchange inside the resident-iteration launch (ictr_resident.hip, "sharded resident form"): the mailboxes of
+// an ictr_p2p object (ictr_p2p.hip: one per rank, hipIpc-mapped into every peer) as the kernel sees them. world == 1: off.
+constexpr int kXchgMaxWorld = 16;
+constexpr int kXchgPerPair = 64;  // granules per frame pair and rank: [0, 12) b as (hi, lo) pairs, [12, 33) H
+struct ResXchg {
+  unsigned long long *peer[kXchgMaxWorld];  // every rank's mailbox as mapped into this process (own rank: the local one)
+  unsigned long long *local;
+  int rank, world;
+  long long cap;     // granules per (parity, rank) slot of a mailbox
+  unsigned *xseq;    // [B] exchanges done so far per frame pair (device memory; every rank counts alike)
+};
+
 struct DevTrace {
   ictr_trace_rec *rec;
   int *count;

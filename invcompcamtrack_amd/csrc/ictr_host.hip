@@ -45,7 +45,7 @@ bool defer_h(const EngineDev &, int);
 hipError_t launch_track1(const EngineDev &, const LevelCam *, int, int, const void *, ProbState *, hipStream_t,
                          const T1Team *);
 hipError_t launch_level_resident(const EngineDev &, const LevelCam &, int, int, int, int, int, int, unsigned,
-                                 unsigned long long, unsigned long long *, int *, int, int, hipStream_t);
+                                 unsigned long long, unsigned long long *, int *, int, int, const ResXchg *, hipStream_t);
 hipError_t launch_debug_transpose_reduce(const float *, float *, int *, int *, int, hipStream_t);
 size_t resident_mail_bytes(int, int);
 int resident_points_per_workgroup(int);
@@ -779,6 +779,9 @@ struct ictr_batch {
   std::vector<hipEvent_t> evk;  // 2 per (level, iteration): around the accumulate kernel alone
   int evk_iters = 0;
   bool evk_valid = true;  // the per-iteration kernel events of the last tracking were recorded (not in the resident form)
+  ResXchg xchg = {};  // sharded resident form (ictr_batch_set_peer_exchange): xchg.world > 1 = the resident launches sum
+                     // H and b over the ranks themselves
+  unsigned *d_xseq = nullptr;  // [B] exchange counters of that form
   int packed = 0;    // every reference pyramid of the current tracking has the interleaved planes
   int otf = 0;       // ... is builder-made (1), and some of them image-only (2): see EngineDev.otf
   int maxpts = 0;    // largest nopoints over the problems of the current tracking (set by ictr_batch_begin)
@@ -832,6 +835,7 @@ static void batch_free(ictr_batch *b) {
   if (b->h_team_err) (void)hipHostFree(b->h_team_err);
   if (b->d_team_mail) (void)hipFree(b->d_team_mail);
   if (b->d_res_mail) (void)hipFree(b->d_res_mail);
+  if (b->d_xseq) (void)hipFree(b->d_xseq);
   b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
@@ -985,6 +989,32 @@ extern "C" int ictr_batch_set_team(ictr_batch *b, int target_points, int min_poi
   b->team_hi = max_points;
   return ICTR_OK;
 }
+extern "C" int ictr_p2p_fill_xchg_(const ictr_p2p *p, ictr::ResXchg *x);
+// Sharded resident form: the batch holds this rank's SHARD of every problem's points; its resident-iteration launches
+// then add H (once per level) and b (once per iteration) over the ranks themselves -- the solver workgroup of a frame
+// pair writes its sums into every rank's mailbox and polls its own (ictr_p2p.hip's one-hop protocol, inside the launch).
+// p: a connected ictr_p2p of at least 64 granules per problem, the same on every rank; NULL: back to a plain batch.
+// Every rank must track the same sequence of (problems, levels, iteration limits); the ranks' loop decisions stay in
+// lockstep because every rank solves on identical sums. Needs the resident form (8x8 patches, no robustness option, no
+// patch normalisation); a tracking that cannot take it fails with ICTR_ERR_STATE rather than run unsynchronised.
+extern "C" int ictr_batch_set_peer_exchange(ictr_batch *b, ictr_p2p *p) {
+  if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
+  if (!p) {
+    memset(&b->xchg, 0, sizeof(b->xchg));
+    return ICTR_OK;
+  }
+  ResXchg x;
+  if (ictr_p2p_fill_xchg_(p, &x)) return fail(ICTR_ERR_STATE, "set_peer_exchange: the p2p object is not connected");
+  if (x.cap < (long long)kXchgPerPair * b->B)
+    return fail(ICTR_ERR_INVALID, "set_peer_exchange: the mailboxes hold %lld granules per rank, %d x %d needed", x.cap,
+                kXchgPerPair, b->B);
+  if (!b->d_xseq) HIPCHK(hipMalloc((void **)&b->d_xseq, sizeof(unsigned) * b->B));
+  HIPCHK(hipMemsetAsync(b->d_xseq, 0, sizeof(unsigned) * b->B, b->stream));
+  x.xseq = b->d_xseq;
+  b->xchg = x;
+  return ICTR_OK;
+}
+
 extern "C" int ictr_batch_set_variant(ictr_batch *b, int variant) {
   if (!b) return fail(ICTR_ERR_INVALID, "batch is NULL");
   b->variant = variant;
@@ -1288,6 +1318,7 @@ static int track1_team(const ictr_batch *b) {
 static bool use_track1(const ictr_batch *b) {
   const int v = engine_variant(b);
   if (b->sharded || b->timing || (v & 8192)) return false;
+  if (b->xchg.world > 1) return false;  // sharded resident form: only k_level_resident exchanges with the peer ranks
   if (b->maxpts < 1) return false;
   if (track1_team(b) > 1) return true;
   if ((size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS
@@ -1513,24 +1544,25 @@ static ResPlan resident_plan(const ictr_batch *b) {
   const int v = engine_variant(b);
   if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !(b->packed || b->otf == 2))
     return p;
-  if (b->maxpts < min_pts || b->op->maxiter < 1) return p;
+  const bool xchg = b->xchg.world > 1;  // sharded resident form: any shard size (an empty shard still runs its solvers)
+  if ((b->maxpts < min_pts && !xchg) || b->op->maxiter < 1) return p;
   static const int max_b = env_int("ICTR_RESIDENT_MAXB", 1 << 20);
   if (b->B > max_b && !(v & (1 << 23))) return p;
   static const int max_slots = env_int("ICTR_RESIDENT_SLOTS", 1 << 20);  // experiments: pairs in flight per launch
   static const int force_np = env_int("ICTR_RESIDENT_NP", 0);             // experiments: 16 or 32
   // sixteen patches per wave (twice the workgroups, half the patch loop) when ALL pairs of the batch are then in flight
   // at once; thirty-two (the most templates a CU can hold: four 1080p pairs in flight) otherwise
-  p.fused = (v & (1 << 26)) ? 1 : 0;
+  p.fused = ((v & (1 << 26)) && !xchg) ? 1 : 0;
   for (int np : {16, 32}) {
     if (force_np && np != force_np) continue;
     const int bpc = resident_blocks_per_cu(np, p.fused);
     if (bpc < 1) continue;
     const int q = resident_points_per_workgroup(np);
-    const int parts = (b->maxpts + q - 1) / q;
+    const int parts = std::max(1, (b->maxpts + q - 1) / q);
     const int64_t capacity = (int64_t)bpc * team_cu_count();
     const int slots = (int)std::min<int64_t>(std::min<int64_t>(b->B, max_slots), capacity / (parts + 1));
     if (slots < 1) continue;
-    if (np == 16 && slots < b->B && !force_np) continue;
+    if (np == 16 && slots < b->B && !force_np && !xchg) continue;
     if ((int64_t)((b->B + slots - 1) / slots) * b->op->maxiter >= 4000) return p;  // exchange number: 12 bits of the tag
     p.parts = parts;
     p.slots = slots;
@@ -1578,7 +1610,8 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
   static const int prio_mode = env_int("ICTR_RESIDENT_PRIO", 2);  // rotating wave priorities: 4.29 -> 4.03 ms per 32 pairs (r03 notes)
   return team_launch(weight, s, [&]() -> int {
     HIPCHK(launch_level_resident(e, lc, level, p.np, p.fused, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
-                                 (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, mute, prio_mode, s));
+                                 (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, mute, prio_mode,
+                                 b->xchg.world > 1 ? &b->xchg : nullptr, s));
     return ICTR_OK;
   });
 }
@@ -1652,6 +1685,10 @@ static bool build_graph(ictr_batch *b, const EngineDev &e, const std::string &ke
 static int enqueue_levels(ictr_batch *b) {
   const EngineDev e = engine_dev(b);
   b->last_path = 0;
+  if (b->xchg.world > 1 && resident_plan(b).parts < 1)
+    return fail(ICTR_ERR_STATE, "a peer exchange is set (sharded resident form) but this tracking cannot run in the "
+                                "resident-iteration form (8x8 patches, no robustness option, no patch normalisation, builder-"
+                                "made pyramids, at most 4000 pair-rounds x iterations per level)");
   if (use_track1(b)) {
     LevelCam cams[16];
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);

@@ -167,6 +167,18 @@ extern "C" int ictr_p2p_allreduce(ictr_p2p *p, float *dev_buf, int64_t count, vo
   return ICTR_OK;
 }
 
+// internal (ictr_host.hip): the mailboxes as a kernel argument of the resident-iteration launch (sharded resident form)
+extern "C" int ictr_p2p_fill_xchg_(const ictr_p2p *p, ictr::ResXchg *x) {
+  if (!p || !x || (!p->connected && p->world > 1)) return 1;
+  memset(x, 0, sizeof(*x));
+  for (int r = 0; r < p->world; ++r) x->peer[r] = (unsigned long long *)p->peer[r];
+  x->local = (unsigned long long *)p->mail;
+  x->rank = p->rank;
+  x->world = p->world;
+  x->cap = p->cap;
+  return 0;
+}
+
 // 0: every exchange so far completed; 1: one timed out (a peer did not arrive). Synchronises the device.
 extern "C" int ictr_p2p_error(ictr_p2p *p) {
   if (!p) return 1;

@@ -28,6 +28,8 @@
 // solver workgroup at the start of the pair (what k_level_tail does in the other launch forms); templates and (possibly
 // stale) coefficients come from the buffers that launch wrote: patches, coefficients and projections are bit-identical
 // to the other launch forms, b differs by summation order only.
+#include <string.h>
+
 #include <type_traits>
 
 #include "ictr_dev.h"
@@ -51,6 +53,7 @@ struct ResArgs {
   int dbg_mute;              // debug (variant bit 25): worker `dbg_mute - 1` never posts its sums (time-out test); 0 = off
   int prof_slot;             // ICTR_RES_PROF builds: the slot whose worker 0 / solver report their cycle counters
   int stagger;               // slot s starts s * stagger ticks (100 MHz) late: the pairs in flight on a CU leave lockstep
+  ResXchg x;                 // x.world > 1: the solver workgroups sum H and b over the ranks (one-hop mailbox exchange)
   int prio_mode;             // wave priorities (s_setprio): 0 none; 1 by slot; 2 by slot, rotating with the slot's pair count
   unsigned tag0;             // launch epoch << 12
   unsigned long long limit;  // polling limit, wall_clock64 ticks (100 MHz)
@@ -156,6 +159,46 @@ hipError_t launch_debug_transpose_reduce(const float *vals, float *out, int *pl,
   else
     hipLaunchKernelGGL(k_debug_transpose_reduce<32>, dim3(1), dim3(64), 0, s, vals, out, pl, kl);
   return hipGetLastError();
+}
+
+// Sharded resident form: lanes [0, n) of the solver's wave 0 each hold one local value; it goes as one granule {value,
+// tag} into slot [parity][rank][pair * kXchgPerPair + off + lane] of EVERY rank's mailbox (system-scope stores over the
+// point-to-point links), then the lane polls its own mailbox for the same granule of every rank and adds them in rank
+// order in f64 -- the same bits on every rank, so the redundant solves stay in lockstep (the protocol of ictr_p2p.hip,
+// inside the launch: no kernel boundary, no host, no communicator). Tags live in the upper half of the 32-bit space
+// (the p2p object's own self-test uses the small sequence numbers).
+__device__ __forceinline__ double res_xchg_sum(const ResXchg &x, ResPoll &pc, int pair, unsigned xs, int off, int n, float v,
+                                               int lane) {
+  const unsigned tag = 0x80000000u | xs;
+  const size_t par = (size_t)(xs & 1u) * x.world;
+  const size_t idx = (size_t)pair * kXchgPerPair + off + lane;
+  if (lane < n) {
+    const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+    for (int r = 0; r < x.world; ++r)
+      __hip_atomic_store(x.peer[r] + (par + x.rank) * x.cap + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  double sum = 0.0;
+  bool started = false;
+  unsigned long long t0 = 0;
+  for (int r = 0; r < x.world; ++r) {
+    const unsigned long long *src = x.local + (par + r) * x.cap + idx;
+    unsigned long long g = (unsigned long long)tag << 32;
+    if (lane < n) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    while (!pc.dead && __builtin_amdgcn_ballot_w64((unsigned)(g >> 32) != tag) != 0) {
+      if (!started) {
+        t0 = wall_clock64();
+        started = true;
+      } else if (wall_clock64() - t0 > pc.limit) {  // a peer rank never arrived: flag it, never wait again
+        if (lane == 0) __hip_atomic_store(pc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        pc.dead = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if ((unsigned)(g >> 32) != tag) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    sum += (double)__builtin_bit_cast(float, (unsigned)(g & 0xffffffffu));
+  }
+  return sum;
 }
 
 // sum of a double over aligned groups of eight lanes (every lane of the group gets it)
@@ -317,7 +360,19 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
         sH[tid] = (float)sacc;
       }
       __syncthreads();
+      unsigned xs = 0;  // (sharded resident form) this pair's exchange count, wave 0 only
       if (wave == 0) {
+        float hl = lane < kHUnique ? sH[lane] : 0.0f;
+        if (a.x.world > 1) {  // H of the level = the sum over the ranks' point shards
+          xs = a.x.xseq[b] + 1u;
+          hl = (float)res_xchg_sum(a.x, pc, b, xs, 12, kHUnique, hl, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (every lane has read its sH entry)
+          __builtin_amdgcn_wave_barrier();
+          if (lane < kHUnique) sH[lane] = hl;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         WaveSolver S;
         ws_factor(S, sH[h_unique_index(lane)], lane);
         ws_store_factor(S, sSt, lane);
@@ -359,6 +414,17 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
           double bsum = 0.0;
           if (lane < 6)
             for (int w = 0; w < kResWaves; ++w) bsum += sRed[w][lane];
+          if (a.x.world > 1) {
+            // b is a sum of signed terms: a shard's partial can be much larger than the total, so it travels as a (hi, lo)
+            // pair of floats (lanes 0-5 / 6-11) and the ranks' total is rounded once (as the team form does)
+            xs += 1u;
+            const float hi = (float)bsum;
+            const float lo = (float)(bsum - (double)hi);
+            const float pv = lane < 6 ? hi : lane_gather(lo, lane - 6);
+            const double t = res_xchg_sum(a.x, pc, b, xs, 0, 12, pv, lane);
+            const int l6 = lane + 6;
+            bsum = t + __hiloint2double(lane_gather(__double2hiint(t), l6), lane_gather(__double2loint(t), l6));
+          }
           WaveSolver S;
           float G[12];
           ws_load_state(S, sSt, lane, G);
@@ -385,6 +451,7 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
         active = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sG[12]));
       }
       if (wave == 0) {  // final state of the level (H, factors, pose, loop state) back to the problem's record
+        if (a.x.world > 1 && lane == 0) a.x.xseq[b] = xs;
         const unsigned *src = reinterpret_cast<const unsigned *>(&sSt);
         unsigned *dst = reinterpret_cast<unsigned *>(e.st + b);
         for (int i = lane; i < (int)(sizeof(ProbState) / 4); i += 64) dst[i] = src[i];
@@ -787,8 +854,12 @@ int resident_blocks_per_cu(int np, int fused) {
 }
 hipError_t launch_level_resident(const EngineDev &e, const LevelCam &lc, int level, int np, int fused, int parts, int slots,
                                  int nblk, unsigned tag0, unsigned long long limit, unsigned long long *mail, int *err,
-                                 int dbg_mute, int prio_mode, hipStream_t s) {
+                                 int dbg_mute, int prio_mode, const ResXchg *xchg, hipStream_t s) {
   ResArgs a;
+  if (xchg)
+    a.x = *xchg;
+  else
+    memset(&a.x, 0, sizeof(a.x));
   a.prio_mode = prio_mode;
   {
     const char *ps = getenv("ICTR_RESIDENT_STAGGER");

@@ -332,6 +332,73 @@ class _OnStream:
             self._work.wait()
 
 
+class ResidentShardedTracker:
+    """Sharded RESIDENT form: every rank holds a contiguous block of each problem's points (frames replicated) and runs
+    the resident-iteration launches of its own batch -- one setup launch + ONE launch per level with all iterations
+    inside -- whose solver workgroups add H (once per level) and b (once per iteration) over the ranks THEMSELVES: each
+    writes its sums into every rank's mailbox (hipIpc-mapped, one hop over the point-to-point xGMI links) and polls its
+    own, inside the launch (csrc/ictr_resident.hip res_xchg_sum; csrc/ictr_p2p.hip's protocol). Between two iterations
+    there is no kernel boundary, no host call and no communicator -- the multi-GPU form of the single-GPU headline
+    kernel, where ShardedTracker drives per-iteration phase kernels and a collective from the host.
+
+    ``batch``: a TrackBatch with this rank's shard set (Set3Dpoints) -- NOT in the phase-driven sharded mode. The
+    mailboxes are a P2PDirect object (lock-step set-up with self-test over the torch group; ``ok`` is the same on every
+    rank). Like P2PDirect it has never crossed a real link (one GPU per box in the build pool; two processes on one GPU
+    in tests/test_gpu_p2p.py), hence opt-in: ``bench.py --resident-p2p``."""
+
+    def __init__(self, batch, group=None, dist=None):
+        import torch
+        if dist is None:
+            import torch.distributed as dist
+        self._torch, self._dist, self.group, self.batch = torch, dist, group, batch
+        self.box = P2PDirect(torch, dist, group, 64 * batch.B)
+        self.ok, self.why = self.box.ok, self.box.why
+        local_ok = True
+        if self.ok:
+            try:
+                batch.set_peer_exchange(self.box._h)
+            except Exception as exc:
+                local_ok, self.why = False, repr(exc)
+            if not _agree(torch, dist, group, local_ok):
+                self.close()
+                self.why = self.why or "another rank could not attach the exchange to its batch"
+
+    def track(self):
+        """Enqueue the whole tracking (every level's setup + resident launch); returns without synchronising."""
+        self.batch.track_async()
+
+    def poses(self):
+        """All poses (identical on every rank). A rank whose launch ran into an exchange time-out raises -- and so does
+        every other rank (one MIN all-reduce on the torch group, called by all ranks whatever they saw)."""
+        out, ok = None, True
+        try:
+            out = self.batch.poses()
+        except Exception as exc:
+            ok, self.why = False, repr(exc)
+        if not _agree(self._torch, self._dist, self.group, ok):
+            raise RuntimeError("sharded resident form: an in-launch exchange timed out on " +
+                               ("this rank" if not ok else "a peer rank") + "; the results of this tracking are invalid "
+                               "on EVERY rank" + (f" ({self.why})" if not ok else ""))
+        return out
+
+    def close(self):
+        if getattr(self, "box", None) is not None:
+            try:
+                self._torch.cuda.synchronize()
+                self.batch.set_peer_exchange(None)
+            except Exception:
+                pass
+            self.box.close()
+            self.box = None
+        self.ok = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedTracker:
     """Drives one TrackBatch, or several (groups of problems that are software-pipelined against each other's
     collectives), in sharded mode. Collective path: RcclDirect (in-stream, when asked for and every rank can set it up),

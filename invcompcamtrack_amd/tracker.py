@@ -373,6 +373,12 @@ class TrackBatch:
         """One-launch tracker, team form (ictr_batch_set_team): workgroups per problem = ceil(n / target_points)."""
         check(_lib.load().ictr_batch_set_team(self._h, int(target_points), int(min_points), int(max_points)))
 
+    def set_peer_exchange(self, p2p_handle):
+        """Sharded resident form (ictr_batch_set_peer_exchange): this batch holds one rank's shard of every problem's
+        points; its resident-iteration launches sum H and b over the ranks inside the launch through the mailboxes of a
+        connected ictr_p2p object (None: off)."""
+        check(_lib.load().ictr_batch_set_peer_exchange(self._h, p2p_handle))
+
     def set_robust(self, clean_invisible=False, compositional=False, huber_k=0.0):
         """Behaviour-changing options, off by default (see ictr_batch_set_robust)."""
         flags = (1 if clean_invisible else 0) | (2 if compositional else 0) | (4 if huber_k > 0 else 0)

@@ -241,3 +241,79 @@ def test_p2p_timeout_on_one_rank_fails_the_tracking_on_every_rank():
     assert res[0][3] and res[1][3], res       # ... and BOTH ranks raise
     assert "timed out" in res[0][4] and "timed out" in res[1][4]
     assert res[0][5] and res[1][5]            # mailboxes closed on both
+
+
+def _worker_resident_sharded(rank, world, port, q):
+    """The sharded RESIDENT form (dist.ResidentShardedTracker): every rank's resident-iteration launches exchange H and
+    b with the peer ranks inside the launch; both ranks on cuda:0."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import invcompcamtrack_amd as ic
+    from invcompcamtrack_amd import synth
+    from invcompcamtrack_amd.dist import ResidentShardedTracker, shard_slices
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    lv_f, psz, B, n = 2, 8, 3, 3001
+    scs = [synth.make_scene(320, 256, n_points=n, seed=50 + k, margin=12.0) for k in range(B)]
+    cam = ic.CamClass(lv_f + 1, scs[0]["fc"], scs[0]["cc"], scs[0]["wh"], psz)
+    lo, hi = shard_slices(n, world)[rank]
+    op = ic.optparam(lv_f, 0, psz, 6, 0.01, 0, 0, hi - lo)
+    eng = ic.TrackBatch(cam, op, B)
+    pyr = [(ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)) for sc in scs]
+    for k, sc in enumerate(scs):
+        eng.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, lo:hi]))
+    tr = ResidentShardedTracker(eng)
+    ok, poses, path = tr.ok, None, ""
+    if ok:
+        for _ in range(3):   # three trackings: the pairs' exchange counters carry on across launches
+            for k, sc in enumerate(scs):
+                eng.SetPose(k, sc["p_a"], *pyr[k])
+            tr.track()
+            poses = tr.poses()
+        path = eng.path_name()
+    iters = eng.iterations() if ok else None
+    tr.close()
+    q.put((rank, ok, poses, iters, path, tr.why))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_resident_form_two_processes_one_gpu():
+    """Points of every frame pair split over two ranks; each rank's k_level_resident launches sum H and b over the ranks
+    inside the launch (no collective, no kernel boundary between iterations). Both ranks must end with identical bits,
+    identical iteration counts (early exit on: normdp_ratio 0.01), and the unsharded engine's poses to 2e-5."""
+    import torch.multiprocessing as mp
+    import invcompcamtrack_amd as ic
+    from invcompcamtrack_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_resident_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], ("exchange not available on both ranks", res[0][5], res[1][5])
+    assert "k_level_resident" in res[0][4] and "k_level_resident" in res[1][4]
+    assert np.array_equal(res[0][2], res[1][2])        # identical bits on both ranks
+    assert np.array_equal(res[0][3], res[1][3])        # the early exit stayed in lockstep
+    lv_f, psz, B, n = 2, 8, 3, 3001
+    scs = [synth.make_scene(320, 256, n_points=n, seed=50 + k, margin=12.0) for k in range(B)]
+    cam = ic.CamClass(lv_f + 1, scs[0]["fc"], scs[0]["cc"], scs[0]["wh"], psz)
+    op = ic.optparam(lv_f, 0, psz, 6, 0.01, 0, 0, n)
+    eng = ic.TrackBatch(cam, op, B)
+    keep = []
+    for k, sc in enumerate(scs):
+        pa, pb = ic.Pyramid(sc["img_a"], lv_f, psz), ic.Pyramid(sc["img_b"], lv_f, psz)
+        keep.append((pa, pb))
+        eng.Set3Dpoints(k, sc["pts3d"].copy())
+        eng.SetPose(k, sc["p_a"], pa, pb)
+    eng.track_async()
+    ref = eng.poses()
+    assert np.abs(res[0][2] - ref).max() <= 2e-5, np.abs(res[0][2] - ref).max()
+    assert np.array_equal(res[0][3], eng.iterations())
