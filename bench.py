@@ -85,6 +85,12 @@ def parse():
                          "contiguous blocks (dist.shard_slices; the north star's partition: the patches of one frame "
                          "shard across the GPUs), so the per-iteration all-reduce is exposed instead of amortised; "
                          "value keeps its unit (whole-job aligned Mpix/s), \"scaling\": \"strong\"")
+    ap.add_argument("--resident-p2p", action="store_true",
+                    help="sharded mode: also try the sharded RESIDENT form (dist.ResidentShardedTracker): one setup launch + "
+                         "ONE k_level_resident launch per level and rank, the ranks' H / b sums exchanged inside the launch "
+                         "through hipIpc-mapped mailboxes -- the single-GPU headline kernel on every rank, no collective "
+                         "call between two iterations. Opt-in like --p2p: the link path has only been rehearsed with "
+                         "several processes on one GPU")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (sharded phases + collectives) with a world of 1 (testing)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
@@ -515,7 +521,8 @@ def main():
         # "torch" = torch.distributed (RCCL on its own stream): the default, the only path that has run on real
         # multi-GPU nodes. --rccl-direct adds the in-stream communicator as a candidate (it joins only if its
         # lock-step set-up and self-test succeed on every rank), --p2p the one-shot peer-to-peer exchange.
-        modes = ["torch"] + (["direct"] if args.rccl_direct else []) + (["p2p"] if args.p2p else [])
+        modes = (["torch"] + (["direct"] if args.rccl_direct else []) + (["p2p"] if args.p2p else [])
+                 + (["resident"] if args.resident_p2p else []))
         if args.groups:
             cands = [(m, args.groups) for m in modes]
         else:
@@ -523,17 +530,25 @@ def main():
             # --tune-groups adds the two-group candidates (overlapping launches, higher throughput)
             cands = [(m, 1) for m in modes]
             if args.tune_groups and two:
-                cands += [(m, 2) for m in modes if m != "p2p"]
+                cands += [(m, 2) for m in modes if m not in ("p2p", "resident")]
         if args.rehearse_gloo:
             cands = [c for c in cands if c[0] == "torch"]
         if args.rehearse_p2p:
-            cands = [c for c in cands if c[0] == "p2p"]
+            cands = [c for c in cands if c[0] in ("p2p", "resident")]
+            if args.resident_p2p:
+                cands = [c for c in cands if c[0] == "resident"]
         built, tuning = {}, {}
         for mode, g in cands:
             engines = inp["make_engines"](g, split=True)
-            tracker = ShardedTracker(engines, staged=args.rehearse_gloo, direct=(mode == "direct"), p2p=(mode == "p2p"))
-            have = (mode == "torch" or (mode == "direct" and tracker.direct is not None)
-                    or (mode == "p2p" and tracker.p2p is not None))
+            if mode == "resident":
+                from invcompcamtrack_amd.dist import ResidentShardedTracker
+                tracker = ResidentShardedTracker(engines[0])
+                tracker.batches, tracker.direct, tracker.p2p, tracker.resident = engines, None, None, True
+                have = tracker.ok
+            else:
+                tracker = ShardedTracker(engines, staged=args.rehearse_gloo, direct=(mode == "direct"), p2p=(mode == "p2p"))
+                have = (mode == "torch" or (mode == "direct" and tracker.direct is not None)
+                        or (mode == "p2p" and tracker.p2p is not None))
             ok = torch.tensor([1.0 if have else 0.0], dtype=torch.float64,
                               device="cpu" if one_gpu else "cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # a path is a candidate only if every rank has it
@@ -610,7 +625,9 @@ def main():
                        "pixels_per_gn_iteration": pix_per_iter, "kernel_variant": args.variant,
                        "host_pipeline": ("2 step holders alternate, host one step ahead"
                                          if (not sharded and len(holders) == 2) else "none"),
-                       "collective": ((("RCCL in-stream (own communicator)" if tracker.direct is not None
+                       "collective": ((("sharded RESIDENT form: H / b summed over the ranks inside the k_level_resident launches "
+                                        "(one-hop mailbox exchange, no collective call)" if getattr(tracker, "resident", False)
+                                        else "RCCL in-stream (own communicator)" if tracker.direct is not None
                                         else "one-shot P2P mailbox exchange" if getattr(tracker, "p2p", None) is not None
                                         else "torch.distributed (own stream)")
                                        + f", {len(tracker.batches)} group(s) of pairs per rank; tuning ms/step: {tuning}")

@@ -92,3 +92,15 @@ def test_patch_flow_ranges_over_two_ranks_equal_the_single_process_result():
     full = [r for r in res if isinstance(r, list)][0]
     assert full[:3] == [True, True, True] and full[3] > 150
     assert True in [r for r in res if not isinstance(r, list)]
+
+
+@pytest.mark.timeout(900)
+def test_bench_sharded_resident_form_two_ranks():
+    """bench.py --gpus 2 --strong --resident-p2p (rehearsed on one GPU): every rank runs the headline's kernels --
+    k_ref8 + ONE k_level_resident launch per level -- on its half of the points and the ranks' sums meet inside the
+    launches. Same poses as the single-process tracker (2e-5), and the line says which path ran."""
+    one = _bench(["--gpus", "1"])
+    two = _bench(["--gpus", "2", "--strong", "--rehearse-p2p", "--resident-p2p"])
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert "RESIDENT" in two["config"]["collective"], two["config"]["collective"]
+    assert abs(two["pose_err_vs_ground_truth"] - one["pose_err_vs_ground_truth"]) < 2e-5
