@@ -557,11 +557,21 @@ def main():
             key = f"{mode}-{g}"
             built[key] = (engines, tracker)
             if len(cands) > 1:
-                run(1, False)
-                barrier()
-                t_a = time.perf_counter()
-                run(2, False)
-                barrier()
+                try:
+                    run(1, False)
+                    barrier()
+                    t_a = time.perf_counter()
+                    run(2, False)
+                    barrier()
+                except RuntimeError as exc:
+                    # an in-launch / P2P exchange timed out: the trackers raise on EVERY rank together (dist.py), so all
+                    # ranks drop the candidate here and stay in step
+                    if rank == 0:
+                        print(f"[bench] candidate {key} failed ({exc}); dropped", file=sys.stderr, flush=True)
+                    del built[key]
+                    if hasattr(tracker, "close"):
+                        tracker.close()
+                    continue
                 t_g = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64,
                                    device="cpu" if one_gpu else "cuda")
                 dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
