@@ -532,7 +532,7 @@ def main():
             if args.tune_groups and two:
                 cands += [(m, 2) for m in modes if m not in ("p2p", "resident")]
         if args.rehearse_gloo:
-            cands = [c for c in cands if c[0] == "torch"]
+            cands = [c for c in cands if c[0] in ("torch", "resident")]
         if args.rehearse_p2p:
             cands = [c for c in cands if c[0] in ("p2p", "resident")]
             if args.resident_p2p:
