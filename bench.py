@@ -85,6 +85,11 @@ def parse():
                          "contiguous blocks (dist.shard_slices; the north star's partition: the patches of one frame "
                          "shard across the GPUs), so the per-iteration all-reduce is exposed instead of amortised; "
                          "value keeps its unit (whole-job aligned Mpix/s), \"scaling\": \"strong\"")
+    ap.add_argument("--no-resident-p2p", dest="auto_resident", action="store_false",
+                    help="N > 1 on real GPUs: do NOT try the sharded RESIDENT form as a candidate (by default it is tried "
+                         "behind three gates -- the mailboxes' lock-step set-up and self-test succeed on every rank, its "
+                         "poses equal the torch.distributed candidate's to 1e-4 on every rank, and it is faster -- and "
+                         "dropped on every rank together otherwise)")
     ap.add_argument("--resident-p2p", action="store_true",
                     help="sharded mode: also try the sharded RESIDENT form (dist.ResidentShardedTracker): one setup launch + "
                          "ONE k_level_resident launch per level and rank, the ranks' H / b sums exchanged inside the launch "
@@ -521,8 +526,9 @@ def main():
         # "torch" = torch.distributed (RCCL on its own stream): the default, the only path that has run on real
         # multi-GPU nodes. --rccl-direct adds the in-stream communicator as a candidate (it joins only if its
         # lock-step set-up and self-test succeed on every rank), --p2p the one-shot peer-to-peer exchange.
+        auto_res = args.auto_resident and world > 1 and not one_gpu and P == 8
         modes = (["torch"] + (["direct"] if args.rccl_direct else []) + (["p2p"] if args.p2p else [])
-                 + (["resident"] if args.resident_p2p else []))
+                 + (["resident"] if (args.resident_p2p or auto_res) else []))
         if args.groups:
             cands = [(m, args.groups) for m in modes]
         else:
@@ -537,7 +543,7 @@ def main():
             cands = [c for c in cands if c[0] in ("p2p", "resident")]
             if args.resident_p2p:
                 cands = [c for c in cands if c[0] == "resident"]
-        built, tuning = {}, {}
+        built, tuning, tune_poses = {}, {}, {}
         for mode, g in cands:
             engines = inp["make_engines"](g, split=True)
             if mode == "resident":
@@ -561,7 +567,7 @@ def main():
                     run(1, False)
                     barrier()
                     t_a = time.perf_counter()
-                    run(2, False)
+                    tune_poses[key] = run(2, False)
                     barrier()
                 except RuntimeError as exc:
                     # an in-launch / P2P exchange timed out: the trackers raise on EVERY rank together (dist.py), so all
@@ -576,6 +582,16 @@ def main():
                                    device="cpu" if one_gpu else "cuda")
                 dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
                 tuning[key] = float(t_g.item()) / 2 * 1e3
+        if "resident-1" in tuning and "torch-1" in tune_poses:
+            # gate 2: the in-launch exchange must give the collective's poses (summation order differs: float noise)
+            d_ = float(np.abs(np.asarray(tune_poses["resident-1"]) - np.asarray(tune_poses["torch-1"])).max())
+            okp = torch.tensor([1.0 if d_ <= 1e-4 else 0.0], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+            dist.all_reduce(okp, op=dist.ReduceOp.MIN)
+            if float(okp.item()) < 1.0:
+                if rank == 0:
+                    print(f"[bench] candidate resident-1 dropped: poses differ from torch-1 by {d_:.3e}", file=sys.stderr, flush=True)
+                del tuning["resident-1"]
+                built.pop("resident-1")[1].close()
         best = min(tuning, key=tuning.get) if tuning else next(iter(built))
         engines, tracker = built[best]
         built.clear()
