@@ -365,6 +365,9 @@ class ResidentShardedTracker:
 
     def track(self):
         """Enqueue the whole tracking (every level's setup + resident launch); returns without synchronising."""
+        if not self.ok:
+            raise RuntimeError("sharded resident form: the exchange is not available (" + (self.why or "closed") + "); a "
+                               "shard tracked on its own would give a silently wrong pose -- build a new tracker")
         self.batch.track_async()
 
     def poses(self):
@@ -376,9 +379,14 @@ class ResidentShardedTracker:
         except Exception as exc:
             ok, self.why = False, repr(exc)
         if not _agree(self._torch, self._dist, self.group, ok):
+            # the ranks' exchange counters may have parted: the mailboxes are closed on EVERY rank (track() refuses from
+            # now on; a new tracker starts from fresh mailboxes and counters)
+            why = self.why
+            self.close()
+            self.why = why or "a peer rank's exchange timed out"
             raise RuntimeError("sharded resident form: an in-launch exchange timed out on " +
                                ("this rank" if not ok else "a peer rank") + "; the results of this tracking are invalid "
-                               "on EVERY rank" + (f" ({self.why})" if not ok else ""))
+                               "on EVERY rank" + (f" ({why})" if not ok else ""))
         return out
 
     def close(self):
