@@ -177,14 +177,24 @@ __device__ __forceinline__ double res_xchg_sum(const ResXchg &x, ResPoll &pc, in
     for (int r = 0; r < x.world; ++r)
       __hip_atomic_store(x.peer[r] + (par + x.rank) * x.cap + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  // the peers' granules: eight ranks' requests in flight at a time (one fabric round trip for a node of eight), re-polled
+  // until every tag matches; added in rank order
   double sum = 0.0;
   bool started = false;
   unsigned long long t0 = 0;
-  for (int r = 0; r < x.world; ++r) {
-    const unsigned long long *src = x.local + (par + r) * x.cap + idx;
-    unsigned long long g = (unsigned long long)tag << 32;
-    if (lane < n) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    while (!pc.dead && __builtin_amdgcn_ballot_w64((unsigned)(g >> 32) != tag) != 0) {
+  const unsigned long long empty = (unsigned long long)tag << 32;
+  for (int r0 = 0; r0 < x.world; r0 += 8) {
+    unsigned long long g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      g[u] = (lane < n && r0 + u < x.world)
+                 ? __hip_atomic_load(x.local + (par + r0 + u) * x.cap + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                 : empty;
+    while (!pc.dead) {
+      bool miss = false;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) miss |= (unsigned)(g[u] >> 32) != tag;
+      if (__builtin_amdgcn_ballot_w64(miss) == 0) break;  // wave-uniform
       if (!started) {
         t0 = wall_clock64();
         started = true;
@@ -194,9 +204,13 @@ __device__ __forceinline__ double res_xchg_sum(const ResXchg &x, ResPoll &pc, in
         break;
       }
       __builtin_amdgcn_s_sleep(1);
-      if ((unsigned)(g >> 32) != tag) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if ((unsigned)(g[u] >> 32) != tag)
+          g[u] = __hip_atomic_load(x.local + (par + r0 + u) * x.cap + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    sum += (double)__builtin_bit_cast(float, (unsigned)(g & 0xffffffffu));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += (double)__builtin_bit_cast(float, (unsigned)(g[u] & 0xffffffffu));
   }
   return sum;
 }
