@@ -973,3 +973,38 @@ def test_two_host_threads_drive_spin_waiting_launches_at_once(oracle):
     assert not errs, errs
     assert len(out_r) == 10 and len(out_t) == 10
     assert all(np.array_equal(p, ref_r[0]) for p in out_r) and all(np.array_equal(p, ref_t[0]) for p in out_t)
+
+
+@pytest.mark.timeout(600)
+def test_headline_batch_properties_at_full_size():
+    """The headline's configuration itself (32 frame pairs of 32 400 patches at 1080p, resident form: four pairs in
+    flight, eight rounds per slot): 32 copies of ONE problem must come out bit-identical whichever slot and round ran
+    them, and equal the same problem in a batch of 5 (two rounds) to float noise; an identity pair among them returns its
+    start pose exactly; all iterations executed. The reference frame is an image-only pyramid (getgrad = 2)."""
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(1920, 1080, grid_step=8, margin=4.0, jitter=0.35, seed=100)
+    n = sc["pts3d"].shape[1]
+    assert n == 32400
+    op = ic.optparam(2, 0, 8, 10, 0.0, 0, 0, n)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8, getgrad=2), ic.Pyramid(sc["img_b"], 2, 8, getgrad=0)
+    out = {}
+    for B in (32, 5):
+        e = ic.TrackBatch(cam, op, B)
+        for k in range(B):
+            e.Set3Dpoints(k, sc["pts3d"].copy())
+            e.SetPose(k, sc["p_a"], pa, pa if k == 3 else pb)
+        e.track_async()
+        out[B] = e.poses().copy()
+        assert "k_level_resident" in e.path_name()
+        it = e.iterations()
+        assert all(it[k] == (3 if k == 3 else 30) for k in range(B)), it
+        del e
+    p32, p5 = out[32], out[5]
+    assert np.array_equal(p32[3], sc["p_a"].astype(np.float32).astype(np.float64))
+    others = [k for k in range(32) if k != 3]
+    assert all(np.array_equal(p32[k], p32[0]) for k in others)
+    # another batch size: the setup kernel's chunk size follows the batch's total point count, so H is summed in another
+    # order (float noise in the pose); the identity pair is exact either way
+    assert np.abs(p5[0] - p32[0]).max() <= 2e-6 and np.array_equal(p5[3], p32[3])
+    assert np.abs(p32[0] - sc["p_b"]).max() < 1e-3

@@ -5,8 +5,8 @@ import numpy as np
 sys.path.insert(0, ".")
 import invcompcamtrack_amd as ic
 from invcompcamtrack_amd import synth
-B = 32
-mode = sys.argv[1] if len(sys.argv) > 1 else "distinct-grid"   # distinct-grid (the bench) | shared-grid | shared-random | distinct-random
+mode = sys.argv[1] if len(sys.argv) > 1 else "distinct-grid"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32   # distinct-grid (the bench) | shared-grid | shared-random | distinct-random
 if "grid" in mode:
     scs = [synth.make_scene(1920, 1080, grid_step=8, margin=4.0, jitter=0.35, seed=100 + s, tex_seed=1234 + s) for s in range(2)]
 else:
@@ -30,6 +30,6 @@ for r in range(12):
     ts.append(time.perf_counter() - t0)
     a, b = e.level_times()
     setup.append(a.copy()); iters.append(b.copy())
-print(json.dumps({"mode": mode, "ms": round(float(np.median(ts[3:])) * 1e3, 3),
+print(json.dumps({"mode": mode, "B": B, "ms": round(float(np.median(ts[3:])) * 1e3, 3),
                   "setup_us_per_level": [round(float(x) * 1e3, 1) for x in np.median(np.array(setup[3:]), 0)],
                   "resident_us_per_level": [round(float(x) * 1e3, 1) for x in np.median(np.array(iters[3:]), 0)]}))
