@@ -248,6 +248,7 @@ def _worker_resident_sharded(rank, world, port, q):
     b with the peer ranks inside the launch; both ranks on cuda:0."""
     sys.path.insert(0, ROOT)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["ICTR_RESIDENT_SLOTS"] = "2"   # two frame pairs in flight: the five pairs take three rounds per launch
     import torch
     import torch.distributed as dist
     import invcompcamtrack_amd as ic
@@ -255,7 +256,7 @@ def _worker_resident_sharded(rank, world, port, q):
     from invcompcamtrack_amd.dist import ResidentShardedTracker, shard_slices
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    lv_f, psz, B, n = 2, 8, 3, 3001
+    lv_f, psz, B, n = 2, 8, 5, 3001
     scs = [synth.make_scene(320, 256, n_points=n, seed=50 + k, margin=12.0) for k in range(B)]
     cam = ic.CamClass(lv_f + 1, scs[0]["fc"], scs[0]["cc"], scs[0]["wh"], psz)
     lo, hi = shard_slices(n, world)[rank]
@@ -284,7 +285,8 @@ def _worker_resident_sharded(rank, world, port, q):
 def test_sharded_resident_form_two_processes_one_gpu():
     """Points of every frame pair split over two ranks; each rank's k_level_resident launches sum H and b over the ranks
     inside the launch (no collective, no kernel boundary between iterations). Both ranks must end with identical bits,
-    identical iteration counts (early exit on: normdp_ratio 0.01), and the unsharded engine's poses to 2e-5."""
+    identical iteration counts (early exit on: normdp_ratio 0.01), and the unsharded engine's poses to 2e-5. Five frame
+    pairs with two in flight per launch (three rounds: a pair's exchange counter outlives its slot), three trackings."""
     import torch.multiprocessing as mp
     import invcompcamtrack_amd as ic
     from invcompcamtrack_amd import synth
@@ -302,7 +304,7 @@ def test_sharded_resident_form_two_processes_one_gpu():
     assert "k_level_resident" in res[0][4] and "k_level_resident" in res[1][4]
     assert np.array_equal(res[0][2], res[1][2])        # identical bits on both ranks
     assert np.array_equal(res[0][3], res[1][3])        # the early exit stayed in lockstep
-    lv_f, psz, B, n = 2, 8, 3, 3001
+    lv_f, psz, B, n = 2, 8, 5, 3001
     scs = [synth.make_scene(320, 256, n_points=n, seed=50 + k, margin=12.0) for k in range(B)]
     cam = ic.CamClass(lv_f + 1, scs[0]["fc"], scs[0]["cc"], scs[0]["wh"], psz)
     op = ic.optparam(lv_f, 0, psz, 6, 0.01, 0, 0, n)
