@@ -103,8 +103,8 @@ typedef struct ictr_pyramid ictr_pyramid;
  * getgrad: 0 image levels only (a "new" frame); 1 image + gradient planes (the reference's getgrad = true); 2 image
  * levels only, to be used as a REFERENCE frame: the tracker's 8x8 setup kernel forms the gradient patches on the fly
  * from the image plane (same subtraction, same blend, same bits as with the planes) -- a quarter of the memory and of
- * the build's bytes; accepted by trackings that run the 8x8 per-iteration / resident forms (psz 8, no robustness
- * option, more points than the one-launch tracker takes), refused with ICTR_ERR_STATE elsewhere. */
+ * the build's bytes; accepted by trackings with psz 8 and no robustness option (they run the 8x8 per-iteration /
+ * resident forms; small problems lose the one-launch tracker), refused with ICTR_ERR_STATE elsewhere. */
 int ictr_pyramid_create(ictr_pyramid **out, const float *img, int w, int h, int lv_f, int getgrad, int pad);
 /* same, img already in device memory (stays caller-owned; only read during the call) */
 int ictr_pyramid_create_device(ictr_pyramid **out, const float *img_dev, int w, int h, int lv_f, int getgrad,

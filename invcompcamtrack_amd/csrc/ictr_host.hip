@@ -1181,10 +1181,11 @@ static int begin_prepare(ictr_batch *b) {
     if (b->gridx8 >= 64 && !getenv("ICTR_NO_XCD_BANDS"))  // multiple of 8: XCD-aware order (xcd_band_block)
       b->gridx8 = (int)std::min<int64_t>((b->gridx8 + 7) / 8 * 8, capx / 8 * 8);
   }
-  if (b->otf == 2 && (b->P != 8 || b->robust || (engine_variant(b) & 2) || use_track1(b)))
+  if (b->otf == 2 && (b->P != 8 || b->robust || (engine_variant(b) & 2)))
     return fail(ICTR_ERR_STATE, "a reference pyramid without gradient planes (getgrad = 2: gradients formed on the fly) is "
                                 "served by the 8x8 setup kernel k_ref8 only: psz 8, no robustness option, variant bit 1 "
-                                "clear, and a problem size beyond the one-launch tracker's (variant bit 13 forces that)");
+                                "clear (small problems then run the per-iteration launches instead of the one-launch "
+                                "tracker)");
   return ICTR_OK;
 }
 // ... device part: upload states + plane table, clear the trace counter, run step 3 for every problem
@@ -1319,6 +1320,7 @@ static bool use_track1(const ictr_batch *b) {
   const int v = engine_variant(b);
   if (b->sharded || b->timing || (v & 8192)) return false;
   if (b->xchg.world > 1) return false;  // sharded resident form: only k_level_resident exchanges with the peer ranks
+  if (b->otf == 2) return false;  // image-only reference pyramids: only k_ref8 forms the gradient patches on the fly
   if (b->maxpts < 1) return false;
   if (track1_team(b) > 1) return true;
   if ((size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS

@@ -151,16 +151,30 @@ def test_gradients_on_the_fly_give_the_planes_bits(n, margin, cpw, monkeypatch):
     assert np.any((np.abs(gx).sum(axis=(1, 2)) > 0) & (np.abs(gx).min(axis=(1, 2)) == 0))
 
 
-def test_image_only_pyramid_is_refused_where_no_kernel_forms_gradients():
+def test_image_only_pyramid_small_problems_and_refusals():
+    """getgrad = 2 reference pyramids: a small 8x8 problem leaves the one-launch tracker (which reads the gradient planes)
+    for the per-iteration launches and gives THEIR result with a planes pyramid bit for bit; other patch sizes and the
+    patch getter, which no on-the-fly kernel serves, are refused with a message."""
     from invcompcamtrack_amd import synth
     sc = synth.make_scene(320, 256, n_points=60, seed=3)
     op = ic.optparam(2, 0, 8, 3, 0.0, 0, 0, 60)
     cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
-    pa_img, pb = ic.Pyramid(sc["img_a"], 2, 8, getgrad=2), ic.Pyramid(sc["img_b"], 2, 8, getgrad=0)
-    e = ic.TrackBatch(cam, op, 1)
+    pa, pa_img, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_a"], 2, 8, getgrad=2), ic.Pyramid(sc["img_b"], 2, 8, getgrad=0)
+    res = []
+    for ref, variant in ((pa_img, 0), (pa, 8192)):
+        e = ic.TrackBatch(cam, op, 1)
+        e.set_variant(variant)
+        e.Set3Dpoints(0, sc["pts3d"].copy())
+        e.SetPose(0, sc["p_a"], ref, pb)
+        e.track_async()
+        res.append((e.poses().copy(), e.path_name()))
+    assert "k_track1" not in res[0][1] and np.array_equal(res[0][0], res[1][0])
+    op4 = ic.optparam(2, 0, 4, 3, 0.0, 0, 0, 60)
+    cam4 = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 4)
+    e = ic.TrackBatch(cam4, op4, 1)
     e.Set3Dpoints(0, sc["pts3d"].copy())
-    e.SetPose(0, sc["p_a"], pa_img, pb)
-    with pytest.raises(ic.IctrError, match="on the fly"):     # 60 points: the one-launch tracker reads the planes
+    e.SetPose(0, sc["p_a"], ic.Pyramid(sc["img_a"], 2, 4, getgrad=2), ic.Pyramid(sc["img_b"], 2, 4, getgrad=0))
+    with pytest.raises(ic.IctrError, match="on the fly"):
         e.track_async()
     with pytest.raises(ic.IctrError, match="gradient"):
         ic.util_getPatch_grad(pa_img, 0, np.array([[20.0, 20.0]], np.float32), op)
