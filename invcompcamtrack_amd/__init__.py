@@ -3,7 +3,7 @@ per-frame tracking hot path). See DESIGN.md. The HIP library is loaded lazily by
 importing this package never touches the GPU and never falls back to a CPU implementation."""
 from . import _lib  # noqa: F401
 from ._lib import IctrError  # noqa: F401
-from .tracker import (CamClass, OdometerClass, PoseClass, Pyramid, TrackBatch, device_count, ncc_score, optparam,  # noqa: F401
+from .tracker import (CamClass, OdometerClass, PoseClass, Pyramid, TrackBatch, device_count, locality_order, ncc_score, optparam,  # noqa: F401
                       timebase_mark,
                       solve6,
                       util_constructpyramide, util_getPatch, util_getPatch_grad, util_SE3_coeff_to_group,

@@ -18,7 +18,7 @@ import numpy as np
 from . import _lib
 from ._lib import OptParam, TraceRec, check, dp, f32c, f64c, fp
 
-__all__ = ["optparam", "CamClass", "PoseClass", "OdometerClass", "Pyramid", "TrackBatch",
+__all__ = ["optparam", "CamClass", "PoseClass", "OdometerClass", "Pyramid", "TrackBatch", "locality_order",
            "util_constructpyramide", "util_getPatch", "util_getPatch_grad", "ncc_score", "util_SE3_coeff_to_group",
            "util_SE3_group_to_coeff", "solve6", "device_count", "timebase_mark"]
 
@@ -193,6 +193,35 @@ def util_SE3_group_to_coeff(G):
         p = np.empty(6, np.float64)
         L.ictr_se3_group_to_coeff_d(dp(p), dp(G))
     return p
+
+
+def locality_order(pts3d, p, fc, cc):
+    """A permutation that lists the points in the order of the Z-curve (Morton code) of their projection under pose p
+    (6 se(3) coefficients) and the level-0 camera (fc, cc): neighbours in the list are neighbours in the image.
+
+    The tracker keeps the caller's point order (Get2DPoints, the patch buffers and the reference's semantics are in
+    that order), and the dense kernels hand 32-64 CONSECUTIVE points to a wave -- so consecutive points whose windows
+    share cache lines are cheap and scattered ones are not: 32 frame pairs of 32 400 patches at 1080p take 1.00 ms per
+    level-0 launch in grid order and 1.55-1.70 ms in random order (profiles/r03_notes.md). A caller whose points come
+    unordered (feature detectors) can pass ``pts3d[:, order]`` to Set3Dpoints and un-permute what it reads back with
+    ``inverse = np.argsort(order)``. Pure NumPy, no GPU; sums change by summation order only.
+    pts3d: (3, n) float64; returns (n,) int64."""
+    pts3d = np.asarray(pts3d, np.float64)
+    G = util_SE3_coeff_to_group(np.asarray(p, np.float64)).reshape(3, 4)
+    Xc = G[:, :3] @ pts3d + G[:, 3:4]
+    z = np.where(np.abs(Xc[2]) > 1e-12, Xc[2], 1e-12)
+    x = Xc[0] / z * float(fc[0]) + float(cc[0])
+    y = Xc[1] / z * float(fc[1]) + float(cc[1])
+    ok = np.isfinite(x) & np.isfinite(y)
+    xi = np.clip(np.where(ok, x, -1.0), -1.0, 65534.0).astype(np.int64) + 1   # out-of-frame points go to the edges
+    yi = np.clip(np.where(ok, y, -1.0), -1.0, 65534.0).astype(np.int64) + 1
+
+    def spread(v):   # 16 bits -> every second bit of 32
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+    return np.argsort(spread(xi) | (spread(yi) << 1), kind="stable")
 
 
 def solve6(H, b):

@@ -146,3 +146,21 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.IctrError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_locality_order_is_a_permutation_that_makes_neighbours_close():
+    """tracker.locality_order (host NumPy + the library's host exp map, no GPU): a permutation of the points along the
+    Z-curve of their projections, so that the 32-64 consecutive points a wave owns share cache lines."""
+    import numpy as np
+    from invcompcamtrack_amd import locality_order
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(640, 480, n_points=4000, seed=2)
+    order = locality_order(sc["pts3d"], sc["p_a"], sc["fc"], sc["cc"])
+    assert sorted(order.tolist()) == list(range(4000))
+    G = np.eye(4)
+    from invcompcamtrack_amd import util_SE3_coeff_to_group
+    G[:3] = util_SE3_coeff_to_group(np.asarray(sc["p_a"], np.float64)).reshape(3, 4)
+    Xc = G[:3, :3] @ sc["pts3d"] + G[:3, 3:4]
+    px = np.stack([Xc[0] / Xc[2] * sc["fc"][0] + sc["cc"][0], Xc[1] / Xc[2] * sc["fc"][1] + sc["cc"][1]], 1)
+    step = lambda q: np.median(np.abs(np.diff(q, axis=0)).max(1))
+    assert step(px[order]) < 0.15 * step(px)      # consecutive points: a few pixels apart instead of half a frame

@@ -1008,3 +1008,27 @@ def test_headline_batch_properties_at_full_size():
     # order (float noise in the pose); the identity pair is exact either way
     assert np.abs(p5[0] - p32[0]).max() <= 2e-6 and np.array_equal(p5[3], p32[3])
     assert np.abs(p32[0] - sc["p_b"]).max() < 1e-3
+
+
+def test_points_in_locality_order_give_the_same_tracking():
+    """locality_order only permutes the caller's points: same poses up to the order of summation, and what comes back per
+    point (Get2DPoints) is the unordered run's after undoing the permutation."""
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(640, 384, n_points=9000, seed=8)
+    order = ic.locality_order(sc["pts3d"], sc["p_a"], sc["fc"], sc["cc"])
+    inv = np.argsort(order)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    op = ic.optparam(2, 0, 8, 6, 0.0, 0, 0, 9000)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    out = []
+    for pts in (sc["pts3d"], np.ascontiguousarray(sc["pts3d"][:, order])):
+        e = ic.TrackBatch(cam, op, 1)
+        e.Set3Dpoints(0, pts.copy())
+        e.SetPose(0, sc["p_a"], pa, pb)
+        e.track_async()
+        out.append((e.poses()[0].copy(), e.Get2DPoints(0).copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() <= 5e-6
+    M = op.maxpttrack
+    x0, y0 = out[0][1][:9000], out[0][1][M:M + 9000]
+    x1, y1 = out[1][1][:9000], out[1][1][M:M + 9000]
+    assert np.array_equal(x1[inv], x0) and np.array_equal(y1[inv], y0)
