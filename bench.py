@@ -11,29 +11,36 @@ projection + 3 levels x [setup + 10 GN iterations]) of a batch of B independent 
 pair has its own pyramids and patch buffers, so one GN iteration streams B x 33 MB = 1.06 GB, far beyond the 256 MB
 Infinity Cache; measured: 16 pairs 238, 32 pairs 266, 64 pairs 270 Gpix/s -- fixed launch/tail costs amortise).
 Inputs (pyramids, 3-D points) are resident in HBM before the timed region; every step ends with its poses on the
-host. Single-GPU mode: the B pairs of a step are held by S = 2 engines of B/2 pairs on two HIP streams (--streams),
-which run concurrently -- one engine's latency-bound setup kernel, tails and launch gaps overlap the other's HBM-bound
-iteration kernel -- and two such step holders alternate, so that the host prepares step i+1 while the GPU runs step i
-(--no-pipeline: one holder; --streams 1: strictly serial kernels, the round-1 default).
+host. Single-GPU mode (since r03): the B pairs of a step are ONE engine on one stream in the resident-iteration form --
+per level one setup launch (k_ref8) and ONE launch for all iterations (k_level_resident: the templates of four frame
+pairs stay in registers / LDS, B pairs in ceil(B / 4) rounds) -- and two step holders alternate, so that the host
+prepares step i+1 while the GPU runs step i (--no-pipeline: one holder). --variant 2097152 selects the streaming
+kernels (a launch pair per iteration), which run as S = 2 engines of B/2 pairs on two HIP streams (--streams).
 
   value        = aligned pixels / s  (pixels entering the residual, all levels, all problems, all ranks) in Mpix/s
-  roofline     = the GN-iteration kernel k_iter8: algorithmic bytes (16 B per patch pixel: T, Gx, Gy, one
-                 current-frame texel) per launch / duration of a launch running ALONE, measured with
-                 HIP events on the kernel's stream around every launch, vs 8 TB/s HBM3E. With two concurrent engines
-                 the timed launches overlap the other stream's kernels, so the same engines and launches run once more
-                 on ONE stream right after the timed region and roofline.frac is THAT un-overlapped figure
-                 (profiles/recompute_roofline.py derives the same number from the rocprofv3 kernel trace of the same
-                 command); roofline.fair_share keeps the overlapped region's figure, roofline.end_to_end all algorithmic
-                 bytes of a step (iterations 16 B/px + setup 24 B/px) over ms_per_step.
+  roofline     = the dominant kernel, k_level_resident: algorithmic bytes (16 B per patch pixel and GN
+                 iteration -- T, Gx, Gy, one current-frame texel -- x maxiter x the launch's pixels) per launch / mean
+                 launch duration (HIP events on the kernel's stream around every launch; one engine, one stream: nothing
+                 overlaps), vs 8 TB/s HBM3E. The kernel does not MOVE those bytes (templates cross HBM once per level),
+                 so frac exceeds 1: the distance past the streaming formulation's roofline. roofline.resident_bounds
+                 holds what bounds the kernel itself (HBM floor of the bytes it must move; the iteration chain),
+                 roofline.traffic the PMC-measured bytes per launch, roofline.streaming_kernel the streaming kernel
+                 k_iter8 timed on its own after the run (the sharded mode's kernel), roofline.setup_kernel k_ref8,
+                 roofline.end_to_end all algorithmic bytes of a step (16 B/px x maxiter + 24 B/px setup) over ms_per_step.
+                 profiles/recompute_roofline.py derives frac from the rocprofv3 kernel trace of the same command.
   cpu_baseline = the oracle (C restatement of the reference, one thread, -O3 -msse4 -mavx) timed on the same
                  workload for one frame pair (a bounded sample), on this host's cores.
 
-N > 1 (one rank per GPU): the points of every frame pair are sharded over the ranks (each rank owns 32 400 points
-per pair => weak scaling), frames are replicated, and per pair the ranks all-reduce ONE 27-float record per GN
-iteration over RCCL (21 floats of H, filled by a level's first iteration, + 6 floats of b;
-invcompcamtrack_amd/dist.py). `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run as a child
-process, before this process touches torch or the GPU) and relays rank 0's JSON line; under torchrun (WORLD_SIZE set)
-it is a rank.
+N > 1 (one rank per GPU): the points of every frame pair are sharded over the ranks (default: each rank owns 32 400
+points per pair => weak scaling; --strong: ONE set of 32 400 points per pair split over the ranks), frames are
+replicated, and per pair the ranks sum ONE 27-float record per GN iteration (21 floats of H, filled by a level's first
+iteration, + 6 floats of b). Paths: torch.distributed / RCCL driving the streaming form's phase kernels
+(invcompcamtrack_amd/dist.py ShardedTracker; the baseline that has run on real nodes), and the sharded RESIDENT form
+(dist.ResidentShardedTracker: the single-GPU kernels on every rank, the sums exchanged inside the k_level_resident
+launches through hipIpc-mapped mailboxes), which is tried as a tuning candidate behind three all-rank gates and used
+when it passes them and is faster (--no-resident-p2p: never). `python bench.py --gpus N` starts the N ranks itself
+(torch.distributed.run as a child process, before this process touches torch or the GPU) and relays rank 0's JSON line;
+under torchrun (WORLD_SIZE set) it is a rank.
 """
 from __future__ import annotations
 
