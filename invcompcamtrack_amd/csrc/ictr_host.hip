@@ -1316,11 +1316,13 @@ static int track1_team(const ictr_batch *b) {
   if (team < 2 || (int64_t)team * b->B > maxwg) return 1;
   return team;
 }
+static bool resident_takes(const ictr_batch *b);  // (resident_plan(b).parts > 0, defined with the plan below)
 static bool use_track1(const ictr_batch *b) {
   const int v = engine_variant(b);
   if (b->sharded || b->timing || (v & 8192)) return false;
   if (b->xchg.world > 1) return false;  // sharded resident form: only k_level_resident exchanges with the peer ranks
   if (b->otf == 2) return false;  // image-only reference pyramids: only k_ref8 forms the gradient patches on the fly
+  if (b->maxpts < 8193 && resident_takes(b)) return false;  // a large batch of mid-size problems: the resident form
   if (b->maxpts < 1) return false;
   if (track1_team(b) > 1) return true;
   if ((size_t)b->maxpts * 64 > 128 * 1024) return false;  // point records must fit in LDS
@@ -1547,7 +1549,11 @@ static ResPlan resident_plan(const ictr_batch *b) {
   if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !(b->packed || b->otf == 2))
     return p;
   const bool xchg = b->xchg.world > 1;  // sharded resident form: any shard size (an empty shard still runs its solvers)
-  if ((b->maxpts < min_pts && !xchg) || b->op->maxiter < 1) return p;
+  // mid-size problems in LARGE batches also run faster here than as teams of the one-launch tracker (r03, tools/
+  // mid_ab.py: 64 x 1000 points 0.88 -> 0.76 ms, 16 x 3000 0.91 -> 0.56, 256 x 1000 3.39 -> 2.06; 8 x 5000 loses 8 %)
+  static const int64_t batch_total = env_int("ICTR_RESIDENT_BATCH_MINTOTAL", 48000);
+  const bool big_batch = batch_total > 0 && b->B >= 16 && b->maxpts >= 512 && (int64_t)b->B * b->maxpts >= batch_total;
+  if ((b->maxpts < min_pts && !xchg && !big_batch) || b->op->maxiter < 1) return p;
   static const int max_b = env_int("ICTR_RESIDENT_MAXB", 1 << 20);
   if (b->B > max_b && !(v & (1 << 23))) return p;
   static const int max_slots = env_int("ICTR_RESIDENT_SLOTS", 1 << 20);  // experiments: pairs in flight per launch
@@ -1573,6 +1579,7 @@ static ResPlan resident_plan(const ictr_batch *b) {
   }
   return p;
 }
+static bool resident_takes(const ictr_batch *b) { return resident_plan(b).parts > 0; }
 // one level's iterations as ONE resident launch (behind the level's setup launches on the same stream)
 static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc, int level, const ResPlan &p,
                            hipStream_t s) {
