@@ -1549,10 +1549,12 @@ static ResPlan resident_plan(const ictr_batch *b) {
   if (!on || (v & ((1 << 21) | 8192 | 4096)) || (v & 2) || b->P != 8 || b->robust || b->sharded || b->op->dopatchnorm || !(b->packed || b->otf == 2))
     return p;
   const bool xchg = b->xchg.world > 1;  // sharded resident form: any shard size (an empty shard still runs its solvers)
-  // mid-size problems in LARGE batches also run faster here than as teams of the one-launch tracker (r03, tools/
-  // mid_ab.py: 64 x 1000 points 0.88 -> 0.76 ms, 16 x 3000 0.91 -> 0.56, 256 x 1000 3.39 -> 2.06; 8 x 5000 loses 8 %)
+  // batches of mid-size problems with >= 48 000 points together also run faster here than as teams of the one-launch
+  // tracker (r03, tools/mid_ab.py: 64 x 1000 points 0.88 -> 0.76 ms, 16 x 3000 0.91 -> 0.56, 12 x 4000 0.91 -> 0.56,
+  // 8 x 6000 0.97 -> 0.58, 128 x 500 0.85 -> 0.75, 256 x 1000 3.39 -> 2.06; below that total the teams win: 8 x 5000
+  // 0.49 against 0.53, 16 x 2500 0.49 / 0.54, 32 x 800 0.43 / 0.48; so do problems of 300 points at any batch size)
   static const int64_t batch_total = env_int("ICTR_RESIDENT_BATCH_MINTOTAL", 48000);
-  const bool big_batch = batch_total > 0 && b->B >= 16 && b->maxpts >= 512 && (int64_t)b->B * b->maxpts >= batch_total;
+  const bool big_batch = batch_total > 0 && b->maxpts >= 500 && (int64_t)b->B * b->maxpts >= batch_total;
   if ((b->maxpts < min_pts && !xchg && !big_batch) || b->op->maxiter < 1) return p;
   static const int max_b = env_int("ICTR_RESIDENT_MAXB", 1 << 20);
   if (b->B > max_b && !(v & (1 << 23))) return p;

@@ -6,7 +6,8 @@ import numpy as np
 sys.path.insert(0, ".")
 import invcompcamtrack_amd as ic
 from invcompcamtrack_amd import synth
-for n, B in ((1000, 64), (3000, 16), (2000, 32), (5000, 8), (1000, 256), (600, 128)):
+cases = [tuple(int(x) for x in a.split('x')) for a in sys.argv[1:]] or [(1000, 64), (3000, 16), (2000, 32), (5000, 8), (1000, 256), (600, 128)]
+for n, B in cases:
     sc = synth.make_scene(640, 480, n_points=n, seed=5)
     op = ic.optparam(4, 0, 8, 10, 0.0, 0, 0, n)
     cam = ic.CamClass(5, sc["fc"], sc["cc"], sc["wh"], 8)
