@@ -269,9 +269,13 @@ def rec_dense(seconds, cpu_track=None):
     return {**cpu, "name": "dense", "workload": f"ONE dense {w}x{h} frame pair per tracking ({n} 8x8 patches, 3 levels x 10 "
             "iterations), host calls included; and a batch of 4", "value": cases[0]["default_ms"], "unit": "ms per tracking "
             "(1 pair)", "aligned_Mpix_per_s": pix / (cases[0]["default_ms"] * 1e-3) / 1e6, "cases": cases,
-            "kernel": cases[0]["default_kernel"], "algorithmic_bytes_per_launch": None, "frac": None,
-            "note": "latency regime: an iteration is a ~10 us chain (patches from registers, mailbox gather, solve, "
-                    "broadcast), not a stream of T/Gx/Gy from HBM"}
+            "kernel": cases[0]["default_kernel"], "algorithmic_bytes_per_launch": None,
+            # floor: the pair's serial chain -- per level the setup's 12 B read + 12 B written per pixel at 8 TB/s and
+            # maxiter iterations of the 8.2 us chain measured for a pair alone on the chip (profiles/r03_notes.md)
+            "floor_ms": 3 * (24.0 * n * P * P / 8e12 + 10 * 8.2e-6) * 1e3,
+            "frac": 3 * (24.0 * n * P * P / 8e12 + 10 * 8.2e-6) * 1e3 / cases[0]["default_ms"],
+            "note": "latency regime: an iteration is a ~8-10 us chain (patches from registers, mailbox gather, solve, "
+                    "broadcast), not a stream of T/Gx/Gy from HBM; frac = chain floor / measured (host calls included)"}
 
 
 def issue_floor_ms(n_points, levels, maxiter, workgroups=1, waves=8, clock_ghz=2.4):
