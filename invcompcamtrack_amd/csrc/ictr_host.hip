@@ -1562,7 +1562,8 @@ static ResPlan resident_plan(const ictr_batch *b) {
   static const int force_np = env_int("ICTR_RESIDENT_NP", 0);             // experiments: 16 or 32
   // sixteen patches per wave (twice the workgroups, half the patch loop) when ALL pairs of the batch are then in flight
   // at once; thirty-two (the most templates a CU can hold: four 1080p pairs in flight) otherwise
-  p.fused = ((v & (1 << 26)) && !xchg) ? 1 : 0;
+  // (the fused setup gathers from the three reference planes: not with image-only pyramids, not with a peer exchange)
+  p.fused = ((v & (1 << 26)) && !xchg && b->otf != 2) ? 1 : 0;
   for (int np : {16, 32}) {
     if (force_np && np != force_np) continue;
     const int bpc = resident_blocks_per_cu(np, p.fused);
