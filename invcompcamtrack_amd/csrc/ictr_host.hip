@@ -1160,6 +1160,10 @@ static int begin_prepare(ictr_batch *b) {
     if (ph.ref->getgrad == 2) any_image_only = true;
   }
   b->packed = all_packed ? 1 : 0;
+  if (any_image_only && !all_builder)
+    return fail(ICTR_ERR_STATE, "a batch cannot mix image-only reference pyramids (getgrad = 2) with pyramids made from "
+                                "caller-supplied planes: the setup kernel reads either the planes or the image, for all "
+                                "problems of a launch");
   b->otf = !all_builder ? 0 : (any_image_only ? 2 : 1);
 
   b->maxpts = maxpts;

@@ -178,3 +178,28 @@ def test_image_only_pyramid_small_problems_and_refusals():
         e.track_async()
     with pytest.raises(ic.IctrError, match="gradient"):
         ic.util_getPatch_grad(pa_img, 0, np.array([[20.0, 20.0]], np.float32), op)
+
+
+def test_image_only_and_host_plane_pyramids_do_not_mix_in_one_batch(oracle):
+    """One launch serves all problems of a batch with ONE setup path: image-only reference pyramids (gradients on the
+    fly) and pyramids made from caller-supplied planes (whose gradients are whatever the caller computed) cannot share it
+    -- refused with a message, never a kernel reading planes that do not exist."""
+    from invcompcamtrack_amd import synth
+    sc = synth.make_scene(320, 256, n_points=700, seed=3)
+    o = oracle.Pyramid(sc["img_a"], 2, 8)
+    host = ic.Pyramid(lv_f=2, imgpadding=8, wh=(320, 256), host_planes=(o.img, o.dx, o.dy))
+    img_only, pb = ic.Pyramid(sc["img_a"], 2, 8, getgrad=2), ic.Pyramid(sc["img_b"], 2, 8, getgrad=0)
+    op = ic.optparam(2, 0, 8, 3, 0.0, 0, 0, 700)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    e = ic.TrackBatch(cam, op, 2)
+    e.set_variant(8192)
+    for k in range(2):
+        e.Set3Dpoints(k, sc["pts3d"].copy())
+    e.SetPose(0, sc["p_a"], host, pb)
+    e.SetPose(1, sc["p_a"], img_only, pb)
+    with pytest.raises(ic.IctrError, match="mix"):
+        e.track_async()
+    e.SetPose(1, sc["p_a"], host, pb)     # both from caller planes: the planes path, same poses for the same problem
+    e.track_async()
+    p = e.poses()
+    assert np.array_equal(p[0], p[1])
