@@ -168,6 +168,12 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
   v = min(v, dpp_mov<0x140>(v));
   return min(min(rlane(v, 0), rlane(v, 16)), min(rlane(v, 32), rlane(v, 48)));
 }
+__device__ __forceinline__ int row_min_dpp(int v) {  // the minimum over the lane's DPP row (16 lanes), in all of them
+  v = min(v, dpp_mov<0xB1>(v));
+  v = min(v, dpp_mov<0x4E>(v));
+  v = min(v, dpp_mov<0x141>(v));
+  return min(v, dpp_mov<0x140>(v));
+}
 __device__ __forceinline__ float lane_gather(float v, int src_lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
 }

@@ -751,6 +751,37 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     const int ip = i0 + (pv ? lane : 0);
     const float mx = pt2d[ip], my = pt2d[ip + M];
     const bool vis = pv && in_view(mx, my, lc.swo, lc.sho);
+    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
+#ifndef ICTR_REF8_TOUCH
+#define ICTR_REF8_TOUCH 6  // line touches per lane and chunk (0: none)
+#endif
+    // (ST) Touch every cache line of the chunk's windows ONCE before the taps ask for them. The taps of a window are four
+    // loads over the same eleven rows, and neighbouring patches share lines: with a frame that is not in the L2 each of
+    // them finds its line "miss pending" and the L1's tag pipeline stalls until the line arrives -- for every wave of
+    // the CU, the stores included (TCP_PENDING_STALL_CYCLES: 278 us of a 448 us launch; 32 distinct 1080p pairs 448 /
+    // 325 / 275 us per level, with the touches 342 / 282 / 255; profiles/r03_notes.md 10). Lanes 16 g .. 16 g + 15
+    // own the chunk's group g: lane i takes row i of the group's bounding box, touch k the box's k-th line of that row,
+    // so no two lanes of one load and no two loads of a group ask for the same line. Issued before the coefficients
+    // are formed, waited for before the first window. Boxes of scattered points (more than 16 rows or kTouch lines
+    // per row) are not touched.
+    constexpr int kTouch = ST ? ICTR_REF8_TOUCH : 0;
+    float touch[kTouch > 0 ? kTouch : 1];
+    if constexpr (kTouch > 0) {
+      const int kBig = 1 << 28;
+      const int rmin = row_min_dpp(vis ? tp.row0 : kBig), rmax = -row_min_dpp(vis ? -tp.row0 : kBig);
+      const int cmin = row_min_dpp(vis ? tp.col0 : kBig), cmax = -row_min_dpp(vis ? -tp.col0 : kBig);
+      const int li = lane & 15, nrows = rmax - rmin + 11;
+      const unsigned long long a_first = (unsigned long long)(pl.ref + (size_t)(rmin - 2 + li) * sw + (cmin - 2));
+      const unsigned long long a_last = (unsigned long long)(pl.ref + (size_t)(rmin - 2 + li) * sw + (cmax + 8)) + 3;
+      const unsigned long long a0 = a_first & ~127ull;
+      const int nl = (int)(((a_last | 127ull) - a0 + 1) >> 7);
+      const bool box = rmin < kBig && nrows <= 16 && li < nrows && nl <= kTouch;
+#pragma unroll
+      for (int k = 0; k < kTouch; ++k) {
+        touch[k] = 0.0f;
+        if (box && k < nl) touch[k] = *(gconst_f32)(a0 + 128ull * k);
+      }
+    }
     float cx[6], cy[6];
     float4 *c4 = reinterpret_cast<float4 *>(coefb + (size_t)ip * kCoefStride);
     if (vis) {
@@ -763,7 +794,6 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
       cx[0] = a0.x; cx[1] = a0.y; cx[2] = a0.z; cx[3] = a0.w; cx[4] = a1.x; cx[5] = a1.y;
       cy[0] = a1.z; cy[1] = a1.w; cy[2] = a2.x; cy[3] = a2.y; cy[4] = a2.z; cy[5] = a2.w;
     }
-    const Taps tp = make_taps(vis ? mx : 1.0f, vis ? my : 1.0f, 4);
     const int base_v = tp.row0 * sw + tp.col0;
     const int vis_v = vis ? 1 : 0;
     const int tx_v = tp.col0 - padl, ty_v = tp.row0 - padl;  // (OTF) tap a of pixel (0,0) in unpadded image coordinates
@@ -844,6 +874,12 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
     };
     if constexpr (ST) {
       const int inner_v = (tx_v >= 2 && tx_v + 7 <= wl - 2 && ty_v >= 2 && ty_v + 7 <= hl - 2) ? 1 : 0;
+      // the wave waits for its touched lines here (the other waves of the CU carry on) rather than let its taps find
+      // them pending
+      if constexpr (kTouch > 0) {
+#pragma unroll
+        for (int k = 0; k < kTouch; ++k) asm volatile("" ::"v"(touch[k]));
+      }
       for (int g0 = 0; g0 < cnt; g0 += 16) {  // (wave-uniform trip count: cnt is)
         const unsigned vmask = (unsigned)(__builtin_amdgcn_ballot_w64(vis) >> g0) & 0xffffu;  // the group's visible points
 #ifndef ICTR_REF8_D
@@ -852,7 +888,11 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
         constexpr int kD = ICTR_REF8_D;
         TapLoadsOTF W3[kD];
         auto issue_s = [&](int j) {
+#if defined(ICTR_REF8_ABL) && (ICTR_REF8_ABL & 2)  // measurement build: every window = the plane's first (L1 hits)
+          if ((vmask >> j) & 1u) W3[j % kD] = taps_issue_otf(pref + 2 * sw + 2 + (rlane(base_v, g0 + j) & 7), loff, sw);
+#else
           if ((vmask >> j) & 1u) W3[j % kD] = taps_issue_otf(pref + rlane(base_v, g0 + j), loff, sw);
+#endif
         };
         res_static_for<0, kD>([&](auto jc) { issue_s(decltype(jc)::value); });
         TrAcc<16> accS, accX;
@@ -865,9 +905,13 @@ __global__ __launch_bounds__(kBlock) void k_ref8(EngineDev e, LevelCam lc, int l
             taps_blend_otf(W3[j % kD], w.x, w.y, w.z, w.w, rlane(inner_v, g0 + j) != 0, rlane(tx_v, g0 + j) + (lane & 7),
                            rlane(ty_v, g0 + j) + (lane >> 3), wl, hl, t, gx, gy);
             const size_t po = (size_t)(i0 + g0 + j) * 64;
+#if defined(ICTR_REF8_ABL) && (ICTR_REF8_ABL & 1)   // measurement build: no patch stores (the sums keep the blends alive)
+            gx += t * 1e-30f;
+#else
             __builtin_nontemporal_store(t, T + po + lane);
             __builtin_nontemporal_store(gx, Gx + po + lane);
             __builtin_nontemporal_store(gy, Gy + po + lane);
+#endif
           }
           if constexpr (j + kD < 16) issue_s(j + kD);
           accS.template push<j>(gx * gx, gy * gy, lane);
