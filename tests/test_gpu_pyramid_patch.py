@@ -151,6 +151,39 @@ def test_gradients_on_the_fly_give_the_planes_bits(n, margin, cpw, monkeypatch):
     assert np.any((np.abs(gx).sum(axis=(1, 2)) > 0) & (np.abs(gx).min(axis=(1, 2)) == 0))
 
 
+@pytest.mark.parametrize("grid", [True, False])
+def test_line_touches_on_small_planes(grid, monkeypatch):
+    """The static form of the 8x8 setup kernel touches every cache line of a group's windows before its taps (bounding
+    box of 16 patches, rows x 128-byte lines). On a 128 x 96 frame with two more levels (32 x 24 at the coarsest, patches
+    all over the plane and at its border) the boxes span whole planes; scattered points have boxes that are not
+    touched at all. Same bits as the dynamic patch loop (variant bit 28), which touches nothing, and as the planes
+    (bit 27)."""
+    from invcompcamtrack_amd import synth
+    monkeypatch.setenv("ICTR_CPW", "64")
+    w, h = 128, 96
+    sc = (synth.make_scene(w, h, grid_step=8, margin=0.5, jitter=0.35, seed=5) if grid
+          else synth.make_scene(w, h, n_points=900, margin=0.5, seed=6))
+    n = sc["pts3d"].shape[1]
+    op = ic.optparam(2, 0, 8, 3, 0.0, 0, 0, n)
+    cam = ic.CamClass(3, sc["fc"], sc["cc"], sc["wh"], 8)
+    pa, pb = ic.Pyramid(sc["img_a"], 2, 8), ic.Pyramid(sc["img_b"], 2, 8)
+    res = []
+    for variant in (8192, 8192 | (1 << 28), 8192 | (1 << 27)):
+        e = ic.TrackBatch(cam, op, 3)
+        e.set_variant(variant)
+        for k in range(3):
+            e.Set3Dpoints(k, sc["pts3d"].copy())
+            e.SetPose(k, sc["p_a"], pa, pb)
+        e.track_async()
+        p = e.poses()
+        res.append((p, [e.read_buffer(k, q, 64 * n) for k in range(3) for q in (0, 1, 2)]))
+    for k in (1, 2):
+        for x, y in zip(res[0][1], res[k][1]):
+            assert np.array_equal(x, y)
+        assert np.abs(res[0][0] - res[k][0]).max() <= 2e-6
+    assert np.abs(res[0][1][1]).max() > 0.1
+
+
 def test_image_only_pyramid_small_problems_and_refusals():
     """getgrad = 2 reference pyramids: a small 8x8 problem leaves the one-launch tracker (which reads the gradient planes)
     for the per-iteration launches and gives THEIR result with a planes pyramid bit for bit; other patch sizes and the
