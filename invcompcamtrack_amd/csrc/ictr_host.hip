@@ -1588,7 +1588,7 @@ static ResPlan resident_plan(const ictr_batch *b) {
 }
 static bool resident_takes(const ictr_batch *b) { return resident_plan(b).parts > 0; }
 // one level's iterations as ONE resident launch (behind the level's setup launches on the same stream)
-static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc, int level, const ResPlan &p,
+static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc, int level, const ResPlan &p, int nblk,
                            hipStream_t s) {
   const size_t need = resident_mail_bytes(p.parts, p.slots);
   if (need > b->res_mail_bytes) {
@@ -1625,7 +1625,7 @@ static int launch_resident(ictr_batch *b, const EngineDev &e, const LevelCam &lc
   const int mute = (engine_variant(b) & (1 << 25)) ? 1 : 0;  // debug: worker 0 never posts its sums (time-out test)
   static const int prio_mode = env_int("ICTR_RESIDENT_PRIO", 2);  // rotating wave priorities: 4.29 -> 4.03 ms per 32 pairs (r03 notes)
   return team_launch(weight, s, [&]() -> int {
-    HIPCHK(launch_level_resident(e, lc, level, p.np, p.fused, p.parts, p.slots, b->gridx8, b->res_epoch << 12,
+    HIPCHK(launch_level_resident(e, lc, level, p.np, p.fused, p.parts, p.slots, nblk, b->res_epoch << 12,
                                  (unsigned long long)(limit_s * 1e8), b->d_res_mail, b->d_team_err, mute, prio_mode,
                                  b->xchg.world > 1 ? &b->xchg : nullptr, s));
     return ICTR_OK;
@@ -1641,9 +1641,20 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
       const LevelCam lc = level_cam(b->cam, sl);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
-      if (!rp.fused) launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 24), b->cpw, b->gridx8, s);
+      // the setup launch's chunk size by level (the resident launch itself has its own geometry): with the batch's 32
+      // points per wave chunk the coarser levels -- frames that fit the caches -- are faster at 64 (32 pairs x 32 400
+      // points: 339-345 / 265-269 / 240-250 us at levels 0 / 1 / 2 with 32, 364-375 / 253-260 / 214-225 with 64)
+      int cpw_l = b->cpw, g8_l = b->gridx8;
+      static const int split = env_int("ICTR_REF8_CPW_BY_LEVEL", 1);
+      if (split && b->cpw == 32 && sl > 0 && !getenv("ICTR_CPW")) {
+        cpw_l = 64;
+        const int64_t want = (((int64_t)std::max(b->maxpts, 1) + cpw_l - 1) / cpw_l + kWaves - 1) / kWaves;
+        g8_l = (int)std::min<int64_t>(std::max<int64_t>(want, 1), b->gridx8);
+        if (g8_l >= 64) g8_l = std::min((g8_l + 7) / 8 * 8, b->gridx8);
+      }
+      if (!rp.fused) launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 24), cpw_l, g8_l, s);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
-      if (int rc = launch_resident(b, e, lc, sl, rp, s)) return rc;
+      if (int rc = launch_resident(b, e, lc, sl, rp, g8_l, s)) return rc;
       if (events) {
         HIPCHK(hipEventRecord(b->ev[3 * sl + 2], s));
         b->ev_used[sl] = 1;
