@@ -43,7 +43,13 @@ constexpr int kResThreads = 64 * kResWaves;
 // patches (points) per wave: template parameter NP of the kernel, 32 (large batches: four pairs in flight) or 16 (one
 // or two pairs: twice the workgroups, half the patch loop); points per workgroup = kResWaves * NP
 constexpr int kResSlot = 8;                 // granules per worker workgroup in the gather box (6 used)
-constexpr int kResD = 4;                    // current-frame windows in flight per wave (4 registers each)
+#ifndef ICTR_RES_AUX
+#define ICTR_RES_AUX 2  // template loads of the pair prologue: slc (streamed)
+#endif
+#ifndef ICTR_RES_D
+#define ICTR_RES_D 4
+#endif
+constexpr int kResD = ICTR_RES_D;           // current-frame windows in flight per wave (4 registers each)
 
 struct ResArgs {
   LevelCam lc;
@@ -681,14 +687,14 @@ __global__ __launch_bounds__(kResThreads, 4) void k_level_resident(EngineDev e, 
       const int loff = lane * 4;
 #pragma unroll
       for (int j = 0; j < kResPPW; ++j) {
-        Gxy[j].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, loff, j * 256, 2));  // slc: streamed
-        Gxy[j].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, loff, j * 256, 2));
+        Gxy[j].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGx, loff, j * 256, ICTR_RES_AUX));  // slc: streamed
+        Gxy[j].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGy, loff, j * 256, ICTR_RES_AUX));
       }
 #pragma unroll
       for (int j0 = 0; j0 < kResPPW; j0 += 8) {
         float t8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t8[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, loff, (j0 + u) * 256, 2));
+        for (int u = 0; u < 8; ++u) t8[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, loff, (j0 + u) * 256, ICTR_RES_AUX));
 #pragma unroll
         for (int u = 0; u < 8; ++u) tw[(j0 + u) * 64] = t8[u];
       }
