@@ -1641,12 +1641,12 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
       const LevelCam lc = level_cam(b->cam, sl);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
-      // the setup launch's chunk size by level (the resident launch itself has its own geometry): with the batch's 32
-      // points per wave chunk the coarser levels -- frames that fit the caches -- are faster at 64 (32 pairs x 32 400
+      // the setup launch's chunk size by level (the resident launch itself has its own geometry): with the batch's 32 (or
+      // 16) points per wave chunk the coarser levels -- frames that fit the caches -- are faster at 64 (32 pairs x 32 400
       // points: 339-345 / 265-269 / 240-250 us at levels 0 / 1 / 2 with 32, 364-375 / 253-260 / 214-225 with 64)
       int cpw_l = b->cpw, g8_l = b->gridx8;
       static const int split = env_int("ICTR_REF8_CPW_BY_LEVEL", 1);
-      if (split && b->cpw == 32 && sl > 0 && !getenv("ICTR_CPW")) {
+      if (split && (b->cpw == 32 || b->cpw == 16) && sl > 0 && !getenv("ICTR_CPW")) {
         cpw_l = 64;
         const int64_t want = (((int64_t)std::max(b->maxpts, 1) + cpw_l - 1) / cpw_l + kWaves - 1) / kWaves;
         g8_l = (int)std::min<int64_t>(std::max<int64_t>(want, 1), b->gridx8);
