@@ -1641,17 +1641,33 @@ static int enqueue_level_kernels(ictr_batch *b, const EngineDev &e, hipStream_t 
     for (int sl = b->op->lv_f; sl >= b->op->lv_l; --sl) {
       const LevelCam lc = level_cam(b->cam, sl);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 0], s));
-      // the setup launch's chunk size by level (the resident launch itself has its own geometry): with the batch's 32 (or
-      // 16) points per wave chunk the coarser levels -- frames that fit the caches -- are faster at 64 (32 pairs x 32 400
-      // points: 339-345 / 265-269 / 240-250 us at levels 0 / 1 / 2 with 32, 364-375 / 253-260 / 214-225 with 64)
+      // The setup launch's chunk size in the resident path (the resident launch itself has its own geometry; the
+      // batch's chunk size serves the per-iteration kernels). (1) At least 16 points per wave chunk (32 from three
+      // problems on): the setup leaves one H partial per workgroup, and the pair's solver workgroup sums them before the
+      // first iteration -- 2025 of them with the 4-point chunks a single dense pair gets. One / two / four dense 1080p
+      // pairs: 0.42 / 0.52 / 0.73 -> 0.38 / 0.45 / 0.59 ms per tracking. (2) 64 at the coarser levels of batches of
+      // eight or more -- frames that fit the caches: 32 pairs x 32 400 points 339-345 / 265-269 / 240-250 us at levels
+      // 0 / 1 / 2 with 32, 364-375 / 253-260 / 214-225 with 64 (profiles/r03_notes.md 10, 12).
       int cpw_l = b->cpw, g8_l = b->gridx8;
       static const int split = env_int("ICTR_REF8_CPW_BY_LEVEL", 1);
-      if (split && (b->cpw == 32 || b->cpw == 16) && sl > 0 && !getenv("ICTR_CPW")) {
-        cpw_l = 64;
-        const int64_t want = (((int64_t)std::max(b->maxpts, 1) + cpw_l - 1) / cpw_l + kWaves - 1) / kWaves;
-        g8_l = (int)std::min<int64_t>(std::max<int64_t>(want, 1), b->gridx8);
-        if (g8_l >= 64) g8_l = std::min((g8_l + 7) / 8 * 8, b->gridx8);
+      auto blocks_for = [&](int c) {  // workgroups per problem with c points per wave chunk
+        const int64_t want = (((int64_t)std::max(b->maxpts, 1) + c - 1) / c + kWaves - 1) / kWaves;
+        int g = (int)std::min<int64_t>(std::max<int64_t>(want, 1), std::max(b->gridx8, 1));
+        if (g >= 64) g = std::min((g + 7) / 8 * 8, b->gridx8);
+        return g;
+      };
+      if (split && !getenv("ICTR_CPW")) {
+        // ... as long as the launch keeps about two workgroups per CU (16 x 3000 points: 32 would leave 384)
+        const int64_t enough = 2 * (int64_t)team_cu_count() - 16;
+        const int floor_cpw = b->B <= 2 ? 16 : 32;
+        for (int c = floor_cpw; c > cpw_l; c /= 2)
+          if ((int64_t)b->B * blocks_for(c) >= enough) {
+            cpw_l = c;
+            break;
+          }
+        if (sl > 0 && b->B >= 8 && cpw_l >= 16 && (int64_t)b->B * blocks_for(64) >= enough) cpw_l = 64;
       }
+      if (cpw_l != b->cpw) g8_l = blocks_for(cpw_l);
       if (!rp.fused) launch_ref_level(e, lc, sl, b->gridx, engine_variant(b) | 256 | (1 << 24), cpw_l, g8_l, s);
       if (events) HIPCHK(hipEventRecord(b->ev[3 * sl + 1], s));
       if (int rc = launch_resident(b, e, lc, sl, rp, g8_l, s)) return rc;

@@ -143,7 +143,10 @@ def test_gradients_on_the_fly_give_the_planes_bits(n, margin, cpw, monkeypatch):
         for q in range(1, 5):   # T, Gx, Gy, coefficients: bit for bit
             assert np.array_equal(res[0][q], res[k][q]), (k, q, np.abs(res[0][q] - res[k][q]).max())
         # poses: H is summed in another order by the static form (transposing reduction), nothing else differs
-        assert np.abs(res[0][0] - res[k][0]).max() <= (0.0 if cpw == 0 else 2e-6), np.abs(res[0][0] - res[k][0]).max()
+        # (the resident path's setup launches use chunks of at least 16 points: static form for the image plane, dynamic
+        # loop for the gradient planes)
+        tol = 0.0 if (cpw == 0 and n < 8193) else 2e-6
+        assert np.abs(res[0][0] - res[k][0]).max() <= tol, np.abs(res[0][0] - res[k][0]).max()
     assert np.array_equal(res[1][0], res[2][0])   # planes or no planes in the pyramid: the same kernel, the same bits
     assert np.abs(res[0][1]).max() > 1 and np.abs(res[0][2]).max() > 0.1
     # border patches were really among them: some patch has an exactly-zero gradient column / row next to non-zero ones
