@@ -817,6 +817,8 @@ struct ictr_batch {
   bool done_valid = false, up_pending = false;
 };
 
+// the plane table's place behind the B records in their common device block / staging buffer (16-byte aligned)
+static size_t up_planes_offset(int B) { return (sizeof(ProbState) * (size_t)B + 15) / 16 * 16; }
 static int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
   return s ? atoi(s) : dflt;
@@ -839,7 +841,7 @@ static void batch_free(ictr_batch *b) {
   b->d_red = b->d_red_own;
   for (void *p : {(void *)b->d_pt3d, (void *)b->d_pt3d_ref, (void *)b->d_pt2d, (void *)b->d_T, (void *)b->d_Gx,
                   (void *)b->d_Gy, (void *)b->d_coef, (void *)b->d_partH, (void *)b->d_partb, (void *)b->d_red,
-                  (void *)b->d_st, (void *)b->d_planes, (void *)b->d_trace, (void *)b->d_trace_count})
+                  (void *)b->d_st, (void *)b->d_trace, (void *)b->d_trace_count})  // (d_planes lives in d_st's block)
     if (p) hipFree(p);
   delete b;
 }
@@ -938,13 +940,15 @@ extern "C" int ictr_batch_create(ictr_batch **out, const ictr_cam *cam, const ic
   alloc((void **)&b->d_partH, sizeof(float) * B * b->gridx * kPartHStride);
   alloc((void **)&b->d_partb, sizeof(float) * B * b->gridx * kPartBStride);
   alloc((void **)&b->d_red, sizeof(float) * B * kRedStride);
-  alloc((void **)&b->d_st, sizeof(ProbState) * B);
-  alloc((void **)&b->d_planes, sizeof(PlaneSet) * B * L);
+  // the records and the plane table in ONE block: one upload per SetPose round instead of two (each small transfer is an
+  // engine switch of 5-8 us in front of the tracking's first kernel)
+  alloc((void **)&b->d_st, up_planes_offset(B) + sizeof(PlaneSet) * B * L);
+  if (e == hipSuccess) b->d_planes = reinterpret_cast<PlaneSet *>(reinterpret_cast<char *>(b->d_st) + up_planes_offset(B));
   alloc((void **)&b->d_trace, sizeof(ictr_trace_rec) * b->trace_cap);
   alloc((void **)&b->d_trace_count, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_st_pin, sizeof(ProbState) * B, hipHostMallocDefault);
   if (e == hipSuccess)
-    e = hipHostMalloc((void **)&b->h_up_pin, sizeof(ProbState) * B + sizeof(PlaneSet) * B * L, hipHostMallocDefault);
+    e = hipHostMalloc((void **)&b->h_up_pin, up_planes_offset(B) + sizeof(PlaneSet) * B * L, hipHostMallocDefault);
   if (e == hipSuccess && hipHostGetDevicePointer((void **)&b->d_st_mirror, b->h_st_pin, 0) != hipSuccess) {
     (void)hipGetLastError();
     b->d_st_mirror = nullptr;  // no mapped view: final states come back by copy
@@ -1198,18 +1202,19 @@ static int begin_device(ictr_batch *b) {
   {
     const size_t nst = sizeof(ProbState) * b->B, npl = sizeof(PlaneSet) * b->h_planes.size();
     if (b->up_pending) HIPCHK(hipEventSynchronize(b->up_ev));  // the previous upload has left the staging buffer
+    const size_t off = up_planes_offset(b->B);
     memcpy(b->h_up_pin, b->h_st.data(), nst);
-    memcpy(b->h_up_pin + nst, b->h_planes.data(), npl);
-    HIPCHK(hipMemcpyAsync(b->d_st, b->h_up_pin, nst, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_planes, b->h_up_pin + nst, npl, hipMemcpyHostToDevice, b->stream));
+    memcpy(b->h_up_pin + off, b->h_planes.data(), npl);
+    HIPCHK(hipMemcpyAsync(b->d_st, b->h_up_pin, off + npl, hipMemcpyHostToDevice, b->stream));  // (d_planes follows d_st)
     HIPCHK(hipEventRecord(b->up_ev, b->stream));
     b->up_pending = true;
   }
-  HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));
-  if (maxpts > 0) {
+  if (maxpts > 0) {  // (the launch also clears the trace counter)
     LevelCam cams[16];
     for (int l = 0; l < b->nlev; ++l) cams[l] = level_cam(b->cam, l);
     launch_project_ref(engine_dev(b), cams, maxpts, b->stream);
+  } else {
+    HIPCHK(hipMemsetAsync(b->d_trace_count, 0, sizeof(int), b->stream));
   }
   HIPCHK(hipGetLastError());
   return ICTR_OK;

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_project_ref(EngineDev e, AllCams cam
   const int b = blockIdx.y;
   const ProbState &st = e.st[b];
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0 && b == 0 && e.trace.count != nullptr) *e.trace.count = 0;  // the tracking's trace starts here (begin phase)
   if (i >= st.npts) return;
   const float *p3 = e.pt3d + (size_t)b * 3 * e.M;
   float *p3r = e.pt3d_ref + (size_t)b * 3 * e.M;
