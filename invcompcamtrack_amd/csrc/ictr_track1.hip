@@ -51,7 +51,8 @@ struct T1Args {
   LevelCam lc[16];
   int npts_cap;  // record / LDS template capacity in points (>= every problem's npts)
   int dbg;       // ICTR_T1_PROF builds: ablation bits (env ICTR_T1_DBG); otherwise unused
-  int fused_begin;         // 1: `blob` is valid and this launch does ictr_batch_begin's device part too
+  int fused_begin;         // 1: `blob` is valid and this launch does ictr_batch_begin's device part too; 2: the records
+                           // and the plane table are in device memory already, the launch does step 3 (the projections)
   int st_words, pl_words;  // dwords per problem of the blob's two sections
   int cap_w;               // 8x8 form: LDS slots per wave (>= its points, rounded up to whole pipeline steps + prefetch)
   ProbState *host_st;      // pinned host mirror of the final states [B], or nullptr
@@ -80,13 +81,13 @@ __device__ __forceinline__ const float *t1_uni(const float *p) {
   return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ const ProbState *t1_initial_state(const EngineDev &e, const T1Args &a, int b) {
-  return a.fused_begin ? reinterpret_cast<const ProbState *>(a.blob + (size_t)b * a.st_words) : e.st + b;
+  return a.fused_begin == 1 ? reinterpret_cast<const ProbState *>(a.blob + (size_t)b * a.st_words) : e.st + b;
 }
 __device__ __forceinline__ PlaneSet t1_planes(const EngineDev &e, const T1Args &a, int b, int level) {
   // (fused begin: read from the kernel arguments, not back from the table this workgroup has just stored: the scalar
   // cache is not coherent with vector stores of the same launch)
-  const PlaneSet *tab = a.fused_begin ? reinterpret_cast<const PlaneSet *>(a.blob + (size_t)e.B * a.st_words)
-                                      : e.planes;
+  const PlaneSet *tab = a.fused_begin == 1 ? reinterpret_cast<const PlaneSet *>(a.blob + (size_t)e.B * a.st_words)
+                                           : e.planes;
   const PlaneSet v = tab[b * e.nlev + level];
   PlaneSet r;
   r.ref = t1_uni(v.ref);
@@ -101,8 +102,8 @@ __device__ __forceinline__ PlaneSet t1_planes(const EngineDev &e, const T1Args &
 // (team form: workgroup `part` of `team` projects its own points [part q, part q + q) only; part 0 stores the tables)
 __device__ __forceinline__ void t1_fused_begin(const EngineDev &e, const T1Args &a, int b, int tid, int nthr,
                                                int part = 0, int q = 0x7fffffff) {
-  const unsigned *bs = a.blob + (size_t)b * a.st_words;
-  if (part == 0) {
+  const unsigned *bs = a.fused_begin == 1 ? a.blob + (size_t)b * a.st_words : reinterpret_cast<const unsigned *>(e.st + b);
+  if (part == 0 && a.fused_begin == 1) {
     unsigned *ds = reinterpret_cast<unsigned *>(e.st + b);
     for (int i = tid; i < a.st_words; i += nthr) ds[i] = bs[i];
     const unsigned *bp = a.blob + (size_t)e.B * a.st_words + (size_t)b * a.pl_words;
@@ -1026,9 +1027,10 @@ int track1_team_size(int maxpts, int target) {
 size_t track1_team_mail_bytes(int B, int team) { return sizeof(unsigned long long) * (size_t)B * 2 * team * kTeamSlot; }
 
 // blob (may be NULL): [ProbState x B][PlaneSet x B x nlev] for the fused begin; host_st (may be NULL): pinned mirror;
+// project_here (without a blob): the records and the plane table have been uploaded, the launch projects (step 3) itself;
 // tm (may be NULL): team form -- tm->team workgroups of tm->q points per problem, mailbox, tag epoch, error flag
 hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, int waves, const void *blob,
-                         ProbState *host_st, hipStream_t s, const T1Team *tm) {
+                         ProbState *host_st, hipStream_t s, const T1Team *tm, bool project_here) {
   T1Args a;
   for (int l = 0; l < 16; ++l) a.lc[l] = cams[l < e.nlev ? l : 0];
   const bool p8 = e.P == 8 && !e.robust;  // the lean 8x8 form; behaviour-changing options run in the any-size form
@@ -1050,7 +1052,7 @@ hipError_t launch_track1(const EngineDev &e, const LevelCam *cams, int maxpts, i
   a.st_words = (int)(sizeof(ProbState) / 4);
   a.pl_words = (int)(sizeof(PlaneSet) / 4) * e.nlev;
   a.host_st = host_st;
-  a.fused_begin = 0;
+  a.fused_begin = project_here ? 2 : 0;
   if (blob) {
     const size_t bytes = (size_t)e.B * 4 * (a.st_words + a.pl_words);
     if (bytes > sizeof(a.blob)) return hipErrorInvalidValue;
