@@ -547,6 +547,40 @@ def test_updates_match_the_summation_order_free_cpu_path(oracle, w, h, npts, psz
     assert np.abs(po - pg).max() <= POSE_TOL
 
 
+@pytest.mark.parametrize("B,psz,team", [(24, 8, 0), (24, 8, 24), (20, 4, 0)])
+def test_one_launch_projects_and_mirrors_for_batches_beyond_the_argument_blob(B, psz, team):
+    """A batch whose records do not fit the kernel arguments (4 KB) uploads them in one copy; the one-launch tracker then
+    projects (step 3) itself and writes the final records into the pinned host mirror -- no projection launch in
+    front, no read-back copy behind. Every bit (poses, iteration counts, Get2DPoints, the stored state) must equal the
+    form with the separate operations (variant bit 18), over repeated trackings with swapped frames."""
+    sc = scene(256, 224, 90, seed=44 + psz, margin=float(max(12, psz + 9)))
+    op = ic.optparam(3, 0, psz, 6, 0.0, 0, 0, 90)
+    cam = ic.CamClass(4, sc["fc"], sc["cc"], sc["wh"], psz)
+    pa, pb = ic.Pyramid(sc["img_a"], 3, psz), ic.Pyramid(sc["img_b"], 3, psz)
+    out = []
+    for variant in (0, SEPARATE_BEGIN):
+        e = ic.TrackBatch(cam, op, B)
+        e.set_variant(variant)
+        if team:
+            e.set_team(team, 0, 1 << 30)
+        for k in range(B):
+            e.Set3Dpoints(k, np.ascontiguousarray(sc["pts3d"][:, :90 - 7 * (k % 6)].copy()))
+        res = []
+        for rep, (ra, rb) in enumerate(((pa, pb), (pb, pa), (pa, pb))):
+            for k in range(B):
+                e.SetPose(k, sc["p_a"] + 1e-4 * k, ra, rb)
+            e.track_async()
+            res.append((e.poses().copy(), e.iterations().copy(), [e.Get2DPoints(k).copy() for k in range(B)],
+                        [e.read_buffer(k, 8, 40) for k in range(B)]))
+        out.append((res, e.path_name()))
+        assert "k_track1" in e.path_name() and ("workgroups per problem" in e.path_name()) == bool(team), e.path_name()
+    for ra, rb in zip(out[0][0], out[1][0]):
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        assert all(np.array_equal(x, y) for x, y in zip(ra[2], rb[2]))
+        assert all(np.array_equal(x[:18], y[:18]) for x, y in zip(ra[3], rb[3]))  # p, G of the stored state
+    assert np.abs(out[0][0][0][0][:, :3] - sc["p_a"][:3]).max() > 1e-4  # (something was tracked)
+
+
 @pytest.mark.parametrize("B,psz,team", [(1, 8, 0), (3, 8, 0), (2, 4, 0), (1, 5, 0), (1, 8, 16), (3, 8, 24)])
 def test_one_launch_with_begin_phase_equals_separate_operations(oracle, B, psz, team):
     """Small batches go out as ONE launch that carries ictr_batch_begin's device part in its arguments and writes the
