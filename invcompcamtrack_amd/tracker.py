@@ -385,6 +385,7 @@ class TrackBatch:
         self.camobj, self.op, self.B = camobj, op, nproblems
         self._h = C.c_void_p()
         self._keep = {}
+        self._keep_all = None
         check(_lib.load().ictr_batch_create(C.byref(self._h), camobj._h, C.byref(op), nproblems))
 
     def __del__(self):
@@ -444,8 +445,8 @@ class TrackBatch:
         poses = f64c(poses)
         if poses.shape != (self.B, 6):
             raise ValueError(f"SetPoseAll needs a ({self.B}, 6) array of poses, got {poses.shape}")
-        for k in range(self.B):
-            self._keep[k] = (img_ref, img_new)
+        self._keep.clear()
+        self._keep_all = (img_ref, img_new)  # borrowed until the next SetPose of every problem (no loop over 500 problems here)
         check(_lib.load().ictr_batch_setpose_all(self._h, dp(poses), img_ref._h, img_new._h))
 
     def track_async(self):
